@@ -1,0 +1,131 @@
+/*
+ * det_math.h -- ORACLE-SIDE deterministic fp32 elementary functions (plain C).
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle/README.md).  This file is the CPU statement of the
+ * elementary functions the hot path needs (sin for Snake, exp for softmax, tanh, erf for GELU).
+ * The reference computes them with libm / Sleef through torch (e.g. the upstream DAC
+ * `snake()` = x + (alpha+1e-9)^-1 * sin(alpha*x)^2, `torch.tanh`, `softmax`, `nn.GELU()` at
+ * Training/compare_dacvsproposal_5.py:229-243,313).  Those library results are not bit-reproducible
+ * across CPU/GPU, so the oracle fixes ONE sequence of IEEE-754 binary32 operations (fma, mul, add,
+ * div, sqrt, rint -- each correctly rounded and therefore identical on any conforming machine).
+ * The HIP product path has its own independent device implementation of the same operation
+ * sequences (multimodal_vqvae_compression_audio_tactile_amd/csrc/det_math.hpp); the parity tests
+ * require the two to agree BIT FOR BIT, and tests/test_oracle_math.py bounds the error of this file
+ * against double-precision libm (<= 2 ulp-ish, see the test for the exact bounds).
+ *
+ * Build with -ffp-contract=off so that the compiler never fuses or splits what is written here.
+ */
+#ifndef ORACLE_DET_MATH_H
+#define ORACLE_DET_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline float om_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+static inline float om_from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t om_to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* ---- sin(x): 3-term Cody-Waite reduction by pi/2, degree-9 / degree-8 kernels ------------- */
+static inline float om_sin(float x)
+{
+    const float TWO_OVER_PI = 0.636619772367581343f;
+    const float P1 = 1.5703125f;                 /* pi/2 split: 8 significant bits          */
+    const float P2 = 4.837512969970703125e-4f;   /* next 11 bits                            */
+    const float P3 = 7.549789948768648e-8f;      /* remainder                               */
+    float n = rintf(x * TWO_OVER_PI);
+    float r = om_fma(-n, P1, x);
+    r = om_fma(-n, P2, r);
+    r = om_fma(-n, P3, r);
+    int q = (int)n;
+    float r2 = r * r;
+    /* sin kernel: r + r^3 * (S1 + r2*(S2 + r2*(S3 + r2*S4))) */
+    float ps = om_fma(r2, 2.75573137e-06f, -1.98412698e-04f);
+    ps = om_fma(r2, ps, 8.33333333e-03f);
+    ps = om_fma(r2, ps, -1.66666667e-01f);
+    float s = om_fma(r * r2, ps, r);
+    /* cos kernel: 1 - r2/2 + r2^2 * (C1 + r2*(C2 + r2*C3)) */
+    float pc = om_fma(r2, -2.75573144e-07f, 2.48015873e-05f);
+    pc = om_fma(r2, pc, -1.38888889e-03f);
+    pc = om_fma(r2, pc, 4.16666667e-02f);
+    float c = om_fma(r2 * r2, pc, om_fma(r2, -0.5f, 1.0f));
+    float v = (q & 1) ? c : s;
+    return (q & 2) ? -v : v;
+}
+
+/* ---- exp(x) for x <= ~88: n = rint(x*log2e), degree-7 Taylor kernel on |r| <= ln2/2 -------- */
+static inline float om_exp_poly(float r) /* returns exp(r) - 1 for |r| <= 0.3466 */
+{
+    float p = om_fma(r, 1.98412698e-04f, 1.38888889e-03f);
+    p = om_fma(r, p, 8.33333333e-03f);
+    p = om_fma(r, p, 4.16666667e-02f);
+    p = om_fma(r, p, 1.66666667e-01f);
+    p = om_fma(r, p, 0.5f);
+    return om_fma(r * r, p, r);
+}
+
+static inline float om_exp(float x)
+{
+    const float LOG2E = 1.44269504088896341f;
+    const float LN2_HI = 0.693145751953125f;      /* 16 significant bits */
+    const float LN2_LO = 1.42860682030941723e-6f;
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    float n = rintf(x * LOG2E);
+    float r = om_fma(-n, LN2_HI, x);
+    r = om_fma(-n, LN2_LO, r);
+    float e = 1.0f + om_exp_poly(r);
+    int ni = (int)n;                               /* in [-126, 127] by the clamps above */
+    float scale = om_from_bits((uint32_t)(ni + 127) << 23);
+    return e * scale;
+}
+
+/* ---- tanh(x) ------------------------------------------------------------------------------ */
+static inline float om_tanh(float x)
+{
+    float a = fabsf(x);
+    float res;
+    if (a < 0.17f) {
+        float em1 = om_exp_poly(a + a);            /* expm1(2a), 2a < ln2/2 */
+        res = em1 / (em1 + 2.0f);
+    } else if (a > 10.0f) {
+        res = 1.0f;
+    } else {
+        float t = om_exp(-(a + a));
+        res = (1.0f - t) / (1.0f + t);
+    }
+    return copysignf(res, x);
+}
+
+/* ---- erf(x): Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), odd-extended ------------------- */
+static inline float om_erf(float x)
+{
+    float a = fabsf(x);
+    float t = 1.0f / om_fma(0.3275911f, a, 1.0f);
+    float p = om_fma(t, 1.061405429f, -1.453152027f);
+    p = om_fma(t, p, 1.421413741f);
+    p = om_fma(t, p, -0.284496736f);
+    p = om_fma(t, p, 0.254829592f);
+    p = p * t;
+    float e = om_exp(-(a * a));
+    float res = om_fma(-p, e, 1.0f);
+    return copysignf(res, x);
+}
+
+/* exact-erf GELU as nn.GELU() default: 0.5*x*(1+erf(x/sqrt(2))) */
+static inline float om_gelu(float x)
+{
+    const float RSQRT2 = 0.707106781186547524f;
+    return (0.5f * x) * (1.0f + om_erf(x * RSQRT2));
+}
+
+/* Snake1d: x + (alpha + 1e-9)^-1 * sin(alpha*x)^2   [upstream dac/nn/layers.py snake()] */
+static inline float om_snake(float x, float alpha)
+{
+    float s = om_sin(alpha * x);
+    float inv = 1.0f / (alpha + 1e-9f);
+    return om_fma(inv, s * s, x);
+}
+
+#endif /* ORACLE_DET_MATH_H */
