@@ -1,0 +1,134 @@
+/*
+ * mvq.h -- C ABI of libmvq_hip.so: the MI355X (gfx950) encode -> vector-quantise -> decode hot path of
+ * aymenboudhina/Multimodal_VQVAE_compression_audio_tactile.
+ *
+ * The reference has no FFI: its boundary is the Python object surface its scripts touch
+ * (SURVEY.md section 8b).  Each entry point below names the reference call it replaces
+ * (paths relative to /root/reference).  All pointers are DEVICE pointers (HIP), all tensors fp32,
+ * contiguous, channel-major [B, C, T] exactly as torch lays them out, indices int32 on this ABI
+ * (the Python mirror widens to int64).  `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  Inputs are borrowed and never written; outputs must be caller-allocated.
+ * Every function returns 0 on success or a negative MVQ_E* code; mvq_last_error() gives the text.
+ * No function allocates, frees or synchronises (safe to capture into a hipGraph), except
+ * mvq_device_query().
+ *
+ * Arithmetic contract: every dot product is one fp32 fma chain in the order "input channel ascending,
+ * then tap ascending" starting from +0.0f, followed by  + bias, + residual, snake, tanh  (each optional).
+ * On gfx950 that is what a k-ordered v_mfma_f32_32x32x2_f32 accumulation yields, so results are
+ * bit-reproducible and comparable bit for bit with oracle/c/oracle.c.
+ */
+#ifndef MVQ_H
+#define MVQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVQ_OK 0
+#define MVQ_EINVAL (-1)      /* bad shape / argument                     */
+#define MVQ_EUNSUPPORTED (-2)/* shape outside what the kernels cover     */
+#define MVQ_EHIP (-3)        /* HIP runtime error (launch failure, ...)  */
+
+#define MVQ_ACT_NONE 0
+#define MVQ_ACT_TANH 1
+
+int mvq_abi_version(void);
+const char* mvq_last_error(void);
+/* fills cu_count / lds_bytes / gcn arch name ("gfx950...") of the current device; synchronous. */
+int mvq_device_query(int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len);
+
+/* ---- one-off weight preparation (model load time) -------------------------------------------- */
+
+/* torch.nn.utils.weight_norm fold, dim 0:  w[r,:] = v[r,:] * (g[r] / ||v[r,:]||_2).
+ * Replaces the implicit fold inside every upstream dac WNConv1d / WNConvTranspose1d forward that
+ * dac.DAC.load(...) modules perform (Training/compare_dacvsproposal_5.py:329-338). */
+int mvq_weight_norm_f32(const float* v, const float* g, float* w, int rows, int inner, void* stream);
+
+/* Packed (K-major, zero-padded) weight image used by mvq_conv1d_f32:  wp[(ci*ks + kk) * Mpad + co].
+ * Query the size (in floats) first, then pack from the torch layout w[Cout, Cin, ks]. */
+size_t mvq_conv1d_packed_floats(int cin, int cout, int ks);
+int mvq_conv1d_pack_f32(const float* w, float* wp, int cin, int cout, int ks, void* stream);
+
+/* Same for ConvTranspose1d with kernel = 2*stride (every upstream DecoderBlock): torch layout
+ * w[Cin, Cout, 2*stride] -> polyphase image wp[(ci*2 + j) * Mpad + (co*stride + r)]. */
+size_t mvq_conv_transpose1d_packed_floats(int cin, int cout, int stride);
+int mvq_conv_transpose1d_pack_f32(const float* w, float* wp, int cin, int cout, int stride, void* stream);
+
+/* ---- conv stack primitives ---------------------------------------------------------------------- */
+
+/* y = act( snake_out( conv1d( snake_in(x) ) + bias + residual ) ).
+ * Replaces torch F.conv1d + the surrounding Snake1d / residual add / tanh inside dac Encoder / Decoder /
+ * ResidualUnit, the 1x1 proj_down / proj_up convs (Training/compare_dacvsproposal_5.py:287-288) and the
+ * bias-free nn.Linear layers of CrossPredictor (...:226-228) when applied on channel-major tensors.
+ *   x[B,Cin,Tin], wp from mvq_conv1d_pack_f32, bias[Cout]|NULL, alpha_in[Cin]|NULL (Snake1d before
+ *   the conv), residual[B,Cout,Tout]|NULL, alpha_out[Cout]|NULL (Snake1d after), act MVQ_ACT_*.
+ *   Tout = (Tin + 2*pad - dil*(ks-1) - 1)/stride + 1.   y[B,Cout,Tout]. */
+int mvq_conv1d_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                   const float* residual, const float* alpha_out, float* y,
+                   int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act,
+                   void* stream);
+
+/* y = snake_out( conv_transpose1d( snake_in(x) ) + bias ), kernel = 2*stride, torch `padding` = pad.
+ * Replaces the Snake1d + WNConvTranspose1d at the head of every upstream DecoderBlock.
+ *   Tout = (Tin-1)*stride - 2*pad + 2*stride. */
+int mvq_conv_transpose1d_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                             const float* alpha_out, float* y,
+                             int batch, int cin, int tin, int cout, int stride, int pad, void* stream);
+
+/* ---- vector quantisation ------------------------------------------------------------------------ */
+
+/* ResidualVQEMA.forward (Training/compare_dacvsproposal_5.py:256-265; eval variant with n_books_use
+ * Evaluation/dac_vcpwq_proposed6_latency.py:417-435).  z[B,D,T], books[nb_use,K,D] contiguous.
+ * Per token and book: idx = argmax_k(res.e_k - 0.5*||e_k||^2) (lowest index on ties), q = e[idx],
+ * q_sum = (q_sum + (q - res)) + res, res = res - q.   q_out[B,D,T]; idx_out[nb_use, B*T] may be NULL. */
+int mvq_rvq_ema_forward_f32(const float* z, const float* books, float* q_out, int32_t* idx_out,
+                            int batch, int dim, int t, int nb_use, int k, void* stream);
+
+/* ResidualVQEMA.ema_step (Training/compare_dacvsproposal_5.py:266-277): every book matched against the
+ * SAME tokens X = z_tokens[B,D,T]; used codes move to decay*e + (1-decay)*mean(assigned tokens).
+ * books[nb,K,D] updated in place.  scratch: >= nb*(K*D + K) floats + nb*B*T int32 (see
+ * mvq_rvq_ema_step_scratch_bytes).  Sums are accumulated in token order (deterministic). */
+size_t mvq_rvq_ema_step_scratch_bytes(int batch, int t, int nb, int k, int dim);
+int mvq_rvq_ema_step_f32(const float* z_tokens, float* books, void* scratch,
+                         int batch, int dim, int t, int nb, int k, float decay, void* stream);
+
+/* dac ResidualVectorQuantize.forward in eval mode, first nq_use stages
+ * (`qa, *_ = self.A_QUANT(za)` Training/compare_dacvsproposal_5.py:295; `mdl.encode(x, n_quantizers)`
+ * Evaluation/compare_dacvsproposal_5_eval.py:369).  Weights already weight-norm folded:
+ *   in_w[nq,Dc,C], in_b[nq,Dc], codebook[nq,K,Dc], out_w[nq,C,Dc], out_b[nq,C]   (Dc <= 16).
+ *   z[B,C,T] -> zq[B,C,T], codes[B,nq_use,T] (int32), latents[B,nq_use*Dc,T]. */
+int mvq_dac_rvq_f32(const float* z, const float* in_w, const float* in_b, const float* codebook,
+                    const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
+                    int batch, int c, int t, int nq_use, int k, int dc, void* stream);
+
+/* ---- predictor / glue primitives (CrossPredictor, TokenNorm, PosEnc1D) --------------------------- */
+
+/* y = post_scale * tanh?( LayerNorm_C(x + pe?) ) on channel-major x[B,C,T] (normalise over C, eps, biased
+ * variance).  pe[max_len, C] (row = position) or NULL; positions are 0..T-1 (PosEnc1D restarts per call).
+ * Replaces PosEnc1D + ln_q/ln_kv/ffn[0] (Training/compare_dacvsproposal_5.py:236-238,243) and
+ * torch.tanh(TokenNorm(r)) * scale (...:313-315). */
+int mvq_layernorm_c_f32(const float* x, const float* pe, const float* gamma, const float* beta, float* y,
+                        int batch, int c, int t, float eps, int do_tanh, float post_scale, void* stream);
+
+/* softmax(Q K^T / sqrt(dh)) V per head on channel-major Q[B,C,Tq], K,V[B,C,Tk] -> ctx[B,C,Tq]
+ * (Training/compare_dacvsproposal_5.py:239-242).  Tk may be 0 (ctx = 0).  Tk <= 64. */
+int mvq_attention_f32(const float* q, const float* k, const float* v, float* ctx,
+                      int batch, int heads, int dh, int tq, int tk, void* stream);
+
+/* y = gelu_erf(x) elementwise (nn.GELU() in CrossPredictor.ffn). */
+int mvq_gelu_f32(const float* x, float* y, size_t n, void* stream);
+
+/* y = a - b elementwise (r = zt[..., s:e] - z_pred) on strided [B,C,T] views:
+ * a has time stride 1 and row pitch a_pitch (elements), rows = B*C. */
+int mvq_sub_rows_f32(const float* a, size_t a_pitch, const float* b, size_t b_pitch, float* y, size_t y_pitch,
+                     size_t rows, int t, void* stream);
+/* copy rows (strided) : y[r, :t] = a[r, :t] */
+int mvq_copy_rows_f32(const float* a, size_t a_pitch, float* y, size_t y_pitch, size_t rows, int t, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVQ_H */

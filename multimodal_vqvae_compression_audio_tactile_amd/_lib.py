@@ -1,0 +1,75 @@
+"""ctypes binding of libmvq_hip.so (the C ABI in include/mvq.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``csrc/Makefile``.  There is NO CPU
+fallback: if the shared object is missing or a tensor is not on a HIP device, every op raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+SO_PATH = _PKG / "libmvq_hip.so"
+_lib = None
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "mvq_abi_version": (c_int, []),
+    "mvq_last_error": (c_char_p, []),
+    "mvq_device_query": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_char_p, c_int]),
+    "mvq_weight_norm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mvq_conv1d_packed_floats": (c_size_t, [c_int, c_int, c_int]),
+    "mvq_conv1d_pack_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mvq_conv_transpose1d_packed_floats": (c_size_t, [c_int, c_int, c_int]),
+    "mvq_conv_transpose1d_pack_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mvq_conv1d_f32": (c_int, [c_void_p] * 7 + [c_int] * 9 + [c_void_p]),
+    "mvq_conv_transpose1d_f32": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
+    "mvq_rvq_ema_forward_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "mvq_rvq_ema_step_scratch_bytes": (c_size_t, [c_int] * 5),
+    "mvq_rvq_ema_step_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_float, c_void_p]),
+    "mvq_dac_rvq_f32": (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p]),
+    "mvq_layernorm_c_f32": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float, c_int, c_float, c_void_p]),
+    "mvq_attention_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "mvq_gelu_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mvq_sub_rows_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_int, c_void_p]),
+    "mvq_copy_rows_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_int, c_void_p]),
+}
+
+
+class MvqError(RuntimeError):
+    """Raised when a libmvq_hip entry point returns a negative status."""
+
+
+def build(force: bool = False) -> Path:
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", str(_PKG / "csrc"), "-j8"]
+    if force:
+        args.append("-B")
+    res = subprocess.run(args, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libmvq_hip.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    return SO_PATH
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not SO_PATH.exists():
+            raise MvqError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the MI355X path)")
+        handle = ctypes.CDLL(str(SO_PATH))
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().mvq_last_error()
+        raise MvqError(f"{what} failed ({status}): {msg.decode() if msg else ''}")

@@ -1,0 +1,226 @@
+// api.hip -- the C ABI of libmvq_hip.so (declared in include/mvq.h): argument checks and kernel dispatch.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/mvq.h"
+#include "conv_dispatch.hpp"
+#include "kernels_small.hpp"
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+int hipfail(hipError_t e, const char* what)
+{
+    return fail(MVQ_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int conv_out_len(int tin, int ks, int stride, int dil, int pad)
+{
+    const int span = tin + 2 * pad - dil * (ks - 1) - 1;
+    return span < 0 ? 0 : span / stride + 1;
+}
+}  // namespace
+
+extern "C" {
+
+int mvq_abi_version(void) { return 1; }
+const char* mvq_last_error(void) { return g_err; }
+
+int mvq_device_query(int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hipfail(e, "hipGetDevice");
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return hipfail(e, "hipGetDeviceProperties");
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)p.maxSharedMemoryPerMultiProcessor;
+    if (arch && arch_len > 0) { strncpy(arch, p.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    return MVQ_OK;
+}
+
+int mvq_weight_norm_f32(const float* v, const float* g, float* w, int rows, int inner, void* stream)
+{
+    if (!v || !g || !w || rows <= 0 || inner <= 0) return fail(MVQ_EINVAL, "weight_norm: bad argument");
+    hipError_t e = mvq::launch_weight_norm(v, g, w, rows, inner, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "weight_norm");
+}
+
+size_t mvq_conv1d_packed_floats(int cin, int cout, int ks)
+{
+    if (cin <= 0 || cout <= 0 || ks <= 0) return 0;
+    return (size_t)cin * ks * mvq::conv_mpad(cout);
+}
+
+int mvq_conv1d_pack_f32(const float* w, float* wp, int cin, int cout, int ks, void* stream)
+{
+    if (!w || !wp || cin <= 0 || cout <= 0 || ks <= 0) return fail(MVQ_EINVAL, "conv1d_pack: bad argument");
+    hipError_t e = mvq::launch_pack_conv1d(w, wp, cin, cout, ks, mvq::conv_mpad(cout), S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_pack");
+}
+
+size_t mvq_conv_transpose1d_packed_floats(int cin, int cout, int stride)
+{
+    if (cin <= 0 || cout <= 0 || stride <= 0) return 0;
+    return (size_t)cin * 2 * mvq::conv_mpad(cout * stride);
+}
+
+int mvq_conv_transpose1d_pack_f32(const float* w, float* wp, int cin, int cout, int stride, void* stream)
+{
+    if (!w || !wp || cin <= 0 || cout <= 0 || stride <= 0) return fail(MVQ_EINVAL, "conv_transpose1d_pack: bad argument");
+    hipError_t e = mvq::launch_pack_convtr(w, wp, cin, cout, stride, mvq::conv_mpad(cout * stride), S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv_transpose1d_pack");
+}
+
+int mvq_conv1d_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                   const float* residual, const float* alpha_out, float* y,
+                   int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act, void* stream)
+{
+    if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv1d: null tensor");
+    if (batch < 0 || cin <= 0 || cout <= 0 || tin < 0 || ks <= 0 || stride <= 0 || dil <= 0 || pad < 0)
+        return fail(MVQ_EINVAL, "conv1d: bad shape B=%d Cin=%d Tin=%d Cout=%d ks=%d s=%d d=%d p=%d", batch, cin, tin, cout, ks, stride, dil, pad);
+    if (act != MVQ_ACT_NONE && act != MVQ_ACT_TANH) return fail(MVQ_EINVAL, "conv1d: bad act %d", act);
+    const int tout = conv_out_len(tin, ks, stride, dil, pad);
+    if (batch == 0 || tout == 0) return MVQ_OK;
+    const int mpad = mvq::conv_mpad(cout);
+    const int bm = mvq::conv_tile_bm(cout);
+
+    mvq::ConvArgs a{};
+    a.x = x; a.wp = wp; a.bias = bias; a.alpha_in = alpha_in; a.residual = residual; a.alpha_out = alpha_out; a.y = y;
+    a.B = batch; a.Cin = cin; a.Tin = tin; a.Cout = cout; a.Tout = tout; a.pad = pad; a.Mpad = mpad;
+    a.Mrows = cout; a.Ncols = tout; a.act = act; a.up_s = 1; a.up_p = 0;
+
+    hipError_t e = hipErrorInvalidValue;
+    const bool dense = cout >= 32 && cin >= 32;      // a dense (channels x kernel) tile exists
+    if (dense) {
+        if (ks == 7 && stride == 1 && cin % 8 == 0) e = mvq::launch_conv_k7(a, dil, bm, S(stream));
+        else if (ks == 1 && stride == 1 && dil == 1 && cin % 32 == 0) e = mvq::launch_conv_k1k3(a, 1, bm, S(stream));
+        else if (ks == 3 && stride == 1 && dil == 1 && cin % 16 == 0) e = mvq::launch_conv_k1k3(a, 3, bm, S(stream));
+        else if (ks == 2 * stride && dil == 1 && cin % 16 == 0) e = mvq::launch_conv_strided(a, stride, bm, S(stream));
+    }
+    if (e == hipErrorInvalidValue) {
+        (void)hipGetLastError();
+        mvq::DirectConvArgs d{x, wp, bias, alpha_in, residual, alpha_out, y, batch, cin, tin, cout, tout, ks, stride, dil, pad, mpad, act};
+        e = mvq::launch_conv1d_direct(d, S(stream));
+    }
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d");
+}
+
+int mvq_conv_transpose1d_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                             const float* alpha_out, float* y,
+                             int batch, int cin, int tin, int cout, int stride, int pad, void* stream)
+{
+    if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv_transpose1d: null tensor");
+    if (batch < 0 || cin <= 0 || cout <= 0 || tin < 0 || stride <= 0 || pad < 0)
+        return fail(MVQ_EINVAL, "conv_transpose1d: bad shape");
+    const int tout = (tin - 1) * stride - 2 * pad + 2 * stride;
+    if (batch == 0 || tin == 0 || tout <= 0) return MVQ_OK;
+    const int mrows = cout * stride;
+    const int mpad = mvq::conv_mpad(mrows);
+    const int bm = mvq::conv_tile_bm(mrows);
+    hipError_t e = hipErrorInvalidValue;
+    if (cin % 32 == 0 && mrows >= 64) {
+        mvq::ConvArgs a{};
+        a.x = x; a.wp = wp; a.bias = bias; a.alpha_in = alpha_in; a.residual = nullptr; a.alpha_out = alpha_out; a.y = y;
+        a.B = batch; a.Cin = cin; a.Tin = tin; a.Cout = cout; a.Tout = tout; a.pad = 1; a.Mpad = mpad;
+        a.Mrows = mrows; a.Ncols = tin + 1; a.act = 0; a.up_s = stride; a.up_p = pad;
+        e = mvq::launch_conv_tr(a, bm, S(stream));
+    }
+    if (e == hipErrorInvalidValue) {
+        (void)hipGetLastError();
+        mvq::DirectConvArgs d{x, wp, bias, alpha_in, nullptr, alpha_out, y, batch, cin, tin, cout, tout, 2 * stride, stride, 1, pad, mpad, 0};
+        e = mvq::launch_convtr_direct(d, S(stream));
+    }
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv_transpose1d");
+}
+
+int mvq_rvq_ema_forward_f32(const float* z, const float* books, float* q_out, int32_t* idx_out,
+                            int batch, int dim, int t, int nb_use, int k, void* stream)
+{
+    if (!z || !q_out || (nb_use > 0 && !books)) return fail(MVQ_EINVAL, "rvq_ema_forward: null tensor");
+    if (batch < 0 || t < 0 || dim <= 0 || dim > 128 || nb_use < 0 || k <= 0)
+        return fail(MVQ_EINVAL, "rvq_ema_forward: bad shape B=%d D=%d T=%d nb=%d K=%d", batch, dim, t, nb_use, k);
+    hipError_t e = mvq::launch_rvq_ema_forward(z, books, q_out, idx_out, batch, dim, t, nb_use, k, 1, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "rvq_ema_forward");
+}
+
+size_t mvq_rvq_ema_step_scratch_bytes(int batch, int t, int nb, int k, int dim)
+{
+    (void)k; (void)dim;
+    return (size_t)nb * batch * t * sizeof(int32_t);
+}
+
+int mvq_rvq_ema_step_f32(const float* z_tokens, float* books, void* scratch,
+                         int batch, int dim, int t, int nb, int k, float decay, void* stream)
+{
+    if (!z_tokens || !books || !scratch) return fail(MVQ_EINVAL, "rvq_ema_step: null tensor");
+    if (batch < 0 || t < 0 || dim <= 0 || dim > 128 || nb <= 0 || k <= 0) return fail(MVQ_EINVAL, "rvq_ema_step: bad shape");
+    if (batch * t == 0) return MVQ_OK;
+    int32_t* idx = reinterpret_cast<int32_t*>(scratch);
+    hipError_t e = mvq::launch_rvq_ema_forward(z_tokens, books, nullptr, idx, batch, dim, t, nb, k, 0, S(stream));
+    if (e != hipSuccess) return hipfail(e, "rvq_ema_step(assign)");
+    e = mvq::launch_ema_update(z_tokens, idx, books, batch, dim, t, nb, k, decay, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "rvq_ema_step(update)");
+}
+
+int mvq_dac_rvq_f32(const float* z, const float* in_w, const float* in_b, const float* codebook,
+                    const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
+                    int batch, int c, int t, int nq_use, int k, int dc, void* stream)
+{
+    if (!z || !zq || !codes || !latents || !in_w || !in_b || !codebook || !out_w || !out_b)
+        return fail(MVQ_EINVAL, "dac_rvq: null tensor");
+    if (batch < 0 || t < 0 || c <= 0 || c % 16 != 0 || c > 1024 || nq_use <= 0 || k <= 0 || dc <= 0 || dc > 16)
+        return fail(MVQ_EINVAL, "dac_rvq: bad shape B=%d C=%d T=%d nq=%d K=%d Dc=%d", batch, c, t, nq_use, k, dc);
+    const size_t lds = ((size_t)c * 16 + (size_t)k * dc + k + 3 * (size_t)dc * 16 + 16 + 2 * 16 * 16) * sizeof(float);
+    if (lds > 160 * 1024) return fail(MVQ_EUNSUPPORTED, "dac_rvq: K*Dc too large for LDS (%zu bytes)", lds);
+    hipError_t e = mvq::launch_dac_rvq(z, in_w, in_b, codebook, out_w, out_b, zq, codes, latents, batch, c, t, nq_use, k, dc, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "dac_rvq");
+}
+
+int mvq_layernorm_c_f32(const float* x, const float* pe, const float* gamma, const float* beta, float* y,
+                        int batch, int c, int t, float eps, int do_tanh, float post_scale, void* stream)
+{
+    if (!x || !gamma || !beta || !y || c <= 0 || batch < 0 || t < 0) return fail(MVQ_EINVAL, "layernorm_c: bad argument");
+    hipError_t e = mvq::launch_layernorm_c(x, pe, gamma, beta, y, batch, c, t, eps, do_tanh, post_scale, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "layernorm_c");
+}
+
+int mvq_attention_f32(const float* q, const float* k, const float* v, float* ctx,
+                      int batch, int heads, int dh, int tq, int tk, void* stream)
+{
+    if (!q || !ctx || (tk > 0 && (!k || !v))) return fail(MVQ_EINVAL, "attention: null tensor");
+    if (batch < 0 || heads <= 0 || dh <= 0 || tq < 0 || tk < 0 || tk > 64) return fail(MVQ_EINVAL, "attention: bad shape (Tk <= 64)");
+    hipError_t e = mvq::launch_attention(q, k, v, ctx, batch, heads, dh, tq, tk, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "attention");
+}
+
+int mvq_gelu_f32(const float* x, float* y, size_t n, void* stream)
+{
+    if ((!x || !y) && n) return fail(MVQ_EINVAL, "gelu: null tensor");
+    hipError_t e = mvq::launch_gelu(x, y, n, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "gelu");
+}
+
+int mvq_sub_rows_f32(const float* a, size_t a_pitch, const float* b, size_t b_pitch, float* y, size_t y_pitch,
+                     size_t rows, int t, void* stream)
+{
+    if ((!a || !b || !y) && rows && t) return fail(MVQ_EINVAL, "sub_rows: null tensor");
+    hipError_t e = mvq::launch_rows(a, a_pitch, b, b_pitch, y, y_pitch, rows, t, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "sub_rows");
+}
+
+int mvq_copy_rows_f32(const float* a, size_t a_pitch, float* y, size_t y_pitch, size_t rows, int t, void* stream)
+{
+    if ((!a || !y) && rows && t) return fail(MVQ_EINVAL, "copy_rows: null tensor");
+    hipError_t e = mvq::launch_rows(a, a_pitch, nullptr, 0, y, y_pitch, rows, t, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "copy_rows");
+}
+
+}  // extern "C"

@@ -1,0 +1,11 @@
+// conv_dispatch.hpp -- entry points of the per-translation-unit MFMA conv instantiations.
+#pragma once
+#include "conv1d_mfma.hpp"
+
+namespace mvq {
+// each returns hipErrorInvalidValue when (shape, tile) has no instantiation in that unit
+hipError_t launch_conv_k7(const ConvArgs& a, int dil, int bm, hipStream_t s);      // ks 7, stride 1, dil 1/3/9
+hipError_t launch_conv_k1k3(const ConvArgs& a, int ks, int bm, hipStream_t s);     // ks 1 or 3, stride 1
+hipError_t launch_conv_strided(const ConvArgs& a, int stride, int bm, hipStream_t s); // ks = 2*stride, stride 2/4/5/8
+hipError_t launch_conv_tr(const ConvArgs& a, int bm, hipStream_t s);               // polyphase ConvTranspose1d
+}  // namespace mvq

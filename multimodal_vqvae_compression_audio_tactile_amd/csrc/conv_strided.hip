@@ -1,0 +1,15 @@
+// conv_strided.hip -- EncoderBlock down-sampling convs: kernel 2*s, stride s, s in {2,4,5,8}.
+#include "conv_dispatch.hpp"
+namespace mvq {
+hipError_t launch_conv_strided(const ConvArgs& a, int stride, int bm, hipStream_t s)
+{
+    if (bm != 128) return hipErrorInvalidValue;
+    switch (stride) {
+        case 2: return launch_conv1d_mfma<4, 2, 1, 16, 2, 2, 2, 2, false>(a, s);
+        case 4: return launch_conv1d_mfma<8, 4, 1, 8, 2, 2, 2, 2, false>(a, s);
+        case 5: return launch_conv1d_mfma<10, 5, 1, 4, 2, 2, 2, 2, false>(a, s);
+        case 8: return launch_conv1d_mfma<16, 8, 1, 4, 2, 2, 2, 2, false>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+}  // namespace mvq

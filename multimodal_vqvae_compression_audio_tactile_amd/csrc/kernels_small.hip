@@ -1,0 +1,303 @@
+// kernels_small.hip -- everything on the path that is not a dense conv GEMM:
+//   weight preparation (weight-norm fold, K-major packing), direct convs for the degenerate ends of the
+//   stacks (Cin = 1, Cout = 1, odd shapes), LayerNorm / attention / GELU of the CrossPredictor and row
+//   glue.  All follow the arithmetic contract of include/mvq.h (sequential fp32 fma chains).
+#include <hip/hip_runtime.h>
+#include "det_math.hpp"
+#include "kernels_small.hpp"
+
+namespace mvq {
+
+// ------------------------------------------------------------------------------------------------
+// weight_norm fold: one thread per dim-0 row, chain over the row (one-off at model load)
+// ------------------------------------------------------------------------------------------------
+__global__ void weight_norm_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                   float* __restrict__ w, int rows, int inner)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* vr = v + (size_t)r * inner;
+    float ss = 0.0f;
+    for (int i = 0; i < inner; ++i) ss = dfma(vr[i], vr[i], ss);
+    const float scale = g[r] / __builtin_sqrtf(ss);
+    for (int i = 0; i < inner; ++i) w[(size_t)r * inner + i] = vr[i] * scale;
+}
+
+hipError_t launch_weight_norm(const float* v, const float* g, float* w, int rows, int inner, hipStream_t s)
+{
+    hipLaunchKernelGGL(weight_norm_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, v, g, w, rows, inner);
+    return hipGetLastError();
+}
+
+// wp[(ci*ks + kk) * Mpad + co] = w[co, ci, kk]   (zero for co >= Cout)
+__global__ void pack_conv1d_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                   int cin, int cout, int ks, int mpad)
+{
+    const size_t total = (size_t)cin * ks * mpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i % mpad);
+        const size_t row = i / mpad;
+        const int kk = (int)(row % ks);
+        const int ci = (int)(row / ks);
+        wp[i] = m < cout ? w[((size_t)m * cin + ci) * ks + kk] : 0.0f;
+    }
+}
+
+hipError_t launch_pack_conv1d(const float* w, float* wp, int cin, int cout, int ks, int mpad, hipStream_t s)
+{
+    const size_t total = (size_t)cin * ks * mpad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_conv1d_kernel, dim3(blocks), dim3(256), 0, s, w, wp, cin, cout, ks, mpad);
+    return hipGetLastError();
+}
+
+// polyphase image of ConvTranspose1d weights w[Cin, Cout, 2S]:
+//   wp[(ci*2 + j) * Mpad + (co*S + r)] = j == 0 ? w[ci, co, r + S] (pairs with x[q-1]) : w[ci, co, r] (x[q])
+__global__ void pack_convtr_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                   int cin, int cout, int S, int mpad)
+{
+    const size_t total = (size_t)cin * 2 * mpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i % mpad);
+        const size_t row = i / mpad;
+        const int j = (int)(row & 1);
+        const int ci = (int)(row >> 1);
+        float val = 0.0f;
+        if (m < cout * S) {
+            const int co = m / S, r = m - co * S;
+            val = w[((size_t)ci * cout + co) * (2 * S) + (j == 0 ? r + S : r)];
+        }
+        wp[i] = val;
+    }
+}
+
+hipError_t launch_pack_convtr(const float* w, float* wp, int cin, int cout, int S, int mpad, hipStream_t s)
+{
+    const size_t total = (size_t)cin * 2 * mpad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_convtr_kernel, dim3(blocks), dim3(256), 0, s, w, wp, cin, cout, S, mpad);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// direct conv1d: one thread per output sample, chain over (ci, kk).  Reads the PACKED weight image so
+// that callers hold one weight format.  Used where the GEMM view has no dense tile: Cin = 1 (encoder
+// input conv), Cout = 1 (decoder output conv + tanh), Cout = 8 and any shape the MFMA units lack.
+// ------------------------------------------------------------------------------------------------
+__global__ void conv1d_direct_kernel(DirectConvArgs a)
+{
+    const size_t total = (size_t)a.B * a.Cout * a.Tout;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % a.Tout);
+        const size_t bc = i / a.Tout;
+        const int co = (int)(bc % a.Cout);
+        const int b = (int)(bc / a.Cout);
+        const float* xb = a.x + (size_t)b * a.Cin * a.Tin;
+        const int g0 = t * a.stride - a.pad;
+        float acc = 0.0f;
+        for (int ci = 0; ci < a.Cin; ++ci) {
+            float al = 0.0f, inv = 0.0f;
+            if (a.alpha_in) { al = a.alpha_in[ci]; inv = 1.0f / (al + 1e-9f); }
+            const float* xr = xb + (size_t)ci * a.Tin;
+            const float* wr = a.wp + (size_t)ci * a.ks * a.Mpad + co;
+            for (int kk = 0; kk < a.ks; ++kk) {
+                const int g = g0 + kk * a.dil;
+                float xv = 0.0f;
+                if (g >= 0 && g < a.Tin) { xv = xr[g]; if (a.alpha_in) xv = det_snake(xv, al, inv); }
+                acc = dfma(wr[(size_t)kk * a.Mpad], xv, acc);
+            }
+        }
+        float v = acc + (a.bias ? a.bias[co] : 0.0f);
+        if (a.residual) v = v + a.residual[i];
+        if (a.alpha_out) { const float al = a.alpha_out[co]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
+        if (a.act == 1) v = det_tanh(v);
+        a.y[i] = v;
+    }
+}
+
+hipError_t launch_conv1d_direct(const DirectConvArgs& a, hipStream_t s)
+{
+    const size_t total = (size_t)a.B * a.Cout * a.Tout;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(conv1d_direct_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// direct conv_transpose1d on the polyphase image (one thread per output sample)
+__global__ void convtr_direct_kernel(DirectConvArgs a)   // a.stride = S, a.pad = P, a.ks unused
+{
+    const size_t total = (size_t)a.B * a.Cout * a.Tout;
+    const int S = a.stride;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % a.Tout);
+        const size_t bc = i / a.Tout;
+        const int co = (int)(bc % a.Cout);
+        const int b = (int)(bc / a.Cout);
+        const int num = t + a.pad;
+        const int q = num / S, r = num - q * S;
+        const float* xb = a.x + (size_t)b * a.Cin * a.Tin;
+        const int m = co * S + r;
+        float acc = 0.0f;
+        for (int ci = 0; ci < a.Cin; ++ci) {
+            float al = 0.0f, inv = 0.0f;
+            if (a.alpha_in) { al = a.alpha_in[ci]; inv = 1.0f / (al + 1e-9f); }
+            const float* xr = xb + (size_t)ci * a.Tin;
+            float x0 = 0.0f, x1 = 0.0f;
+            if (q - 1 >= 0 && q - 1 < a.Tin) { x0 = xr[q - 1]; if (a.alpha_in) x0 = det_snake(x0, al, inv); }
+            if (q < a.Tin) { x1 = xr[q]; if (a.alpha_in) x1 = det_snake(x1, al, inv); }
+            acc = dfma(a.wp[((size_t)ci * 2 + 0) * a.Mpad + m], x0, acc);
+            acc = dfma(a.wp[((size_t)ci * 2 + 1) * a.Mpad + m], x1, acc);
+        }
+        float v = acc + (a.bias ? a.bias[co] : 0.0f);
+        if (a.alpha_out) { const float al = a.alpha_out[co]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
+        a.y[i] = v;
+    }
+}
+
+hipError_t launch_convtr_direct(const DirectConvArgs& a, hipStream_t s)
+{
+    const size_t total = (size_t)a.B * a.Cout * a.Tout;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(convtr_direct_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over C of channel-major x[B,C,T] (+ optional positional-encoding add, tanh, scale).
+// One thread per token; lanes = consecutive t (coalesced); channel loop sequential (the contract).
+// ------------------------------------------------------------------------------------------------
+__global__ void layernorm_c_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ y, int B, int C, int T, float eps, int do_tanh,
+                                   float post_scale)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= B * T) return;
+    const int b = n / T, t = n - b * T;
+    const float* xb = x + (size_t)b * C * T + t;
+    const float* per = pe ? pe + (size_t)t * C : nullptr;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        float v = xb[(size_t)c * T];
+        if (per) v = v + per[c];
+        s = s + v;
+    }
+    const float mean = s / (float)C;
+    float var = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        float v = xb[(size_t)c * T];
+        if (per) v = v + per[c];
+        const float d = v - mean;
+        var = dfma(d, d, var);
+    }
+    const float rstd = 1.0f / __builtin_sqrtf(var / (float)C + eps);
+    float* yb = y + (size_t)b * C * T + t;
+    for (int c = 0; c < C; ++c) {
+        float v = xb[(size_t)c * T];
+        if (per) v = v + per[c];
+        float o = dfma((v - mean) * rstd, gamma[c], beta[c]);
+        if (do_tanh) o = det_tanh(o);
+        if (do_tanh || post_scale != 1.0f) o = post_scale * o;
+        yb[(size_t)c * T] = o;
+    }
+}
+
+hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamma, const float* beta, float* y,
+                              int B, int C, int T, float eps, int do_tanh, float post_scale, hipStream_t s)
+{
+    const int n = B * T;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(layernorm_c_kernel, dim3((n + 63) / 64), dim3(64), 0, s, x, pe, gamma, beta, y, B, C, T, eps,
+                       do_tanh, post_scale);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention core: one thread per (b, head, query); probabilities live in LDS (Tk floats per thread).
+// ------------------------------------------------------------------------------------------------
+__global__ void attention_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                 const float* __restrict__ V, float* __restrict__ ctx,
+                                 int B, int H, int dh, int Tq, int Tk)
+{
+    extern __shared__ float pbuf[];                     // [blockDim.x][Tk]
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= B * H * Tq) return;
+    const int i = n % Tq;
+    const int bh = n / Tq;
+    const int hd = bh % H, b = bh / H;
+    const int C = H * dh;
+    const float* q = Q + ((size_t)b * C + (size_t)hd * dh) * Tq + i;
+    const float* kb = K + ((size_t)b * C + (size_t)hd * dh) * Tk;
+    const float* vb = V + ((size_t)b * C + (size_t)hd * dh) * Tk;
+    float* p = pbuf + (size_t)threadIdx.x * Tk;
+    const float rs = __builtin_sqrtf((float)dh);
+    float m = -__builtin_inff();
+    for (int j = 0; j < Tk; ++j) {
+        float a = 0.0f;
+        for (int d = 0; d < dh; ++d) a = dfma(q[(size_t)d * Tq], kb[(size_t)d * Tk + j], a);
+        a = a / rs;
+        p[j] = a;
+        m = __builtin_fmaxf(m, a);
+    }
+    float l = 0.0f;
+    for (int j = 0; j < Tk; ++j) { const float e = det_exp(p[j] - m); p[j] = e; l = l + e; }
+    for (int j = 0; j < Tk; ++j) p[j] = p[j] / l;
+    float* out = ctx + ((size_t)b * C + (size_t)hd * dh) * Tq + i;
+    for (int d = 0; d < dh; ++d) {
+        float a = 0.0f;
+        for (int j = 0; j < Tk; ++j) a = dfma(p[j], vb[(size_t)d * Tk + j], a);
+        out[(size_t)d * Tq] = a;
+    }
+}
+
+hipError_t launch_attention(const float* q, const float* k, const float* v, float* ctx,
+                            int B, int H, int dh, int Tq, int Tk, hipStream_t s)
+{
+    const int n = B * H * Tq;
+    if (n == 0) return hipSuccess;
+    const int threads = 64;
+    hipLaunchKernelGGL(attention_kernel, dim3((n + threads - 1) / threads), dim3(threads),
+                       (size_t)threads * (Tk > 0 ? Tk : 1) * sizeof(float), s, q, k, v, ctx, B, H, dh, Tq, Tk);
+    return hipGetLastError();
+}
+
+__global__ void gelu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = det_gelu(x[i]);
+}
+
+hipError_t launch_gelu(const float* x, float* y, size_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, y, n);
+    return hipGetLastError();
+}
+
+__global__ void rows_kernel(const float* __restrict__ a, size_t a_pitch, const float* __restrict__ b, size_t b_pitch,
+                            float* __restrict__ y, size_t y_pitch, size_t rows, int T)
+{
+    const size_t total = rows * (size_t)T;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / T;
+        const int t = (int)(i - r * T);
+        float v = a[r * a_pitch + t];
+        if (b) v = v - b[r * b_pitch + t];
+        y[r * y_pitch + t] = v;
+    }
+}
+
+hipError_t launch_rows(const float* a, size_t a_pitch, const float* b, size_t b_pitch, float* y, size_t y_pitch,
+                       size_t rows, int T, hipStream_t s)
+{
+    const size_t total = rows * (size_t)T;
+    if (total == 0) return hipSuccess;
+    size_t blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, a_pitch, b, b_pitch, y, y_pitch, rows, T);
+    return hipGetLastError();
+}
+
+}  // namespace mvq

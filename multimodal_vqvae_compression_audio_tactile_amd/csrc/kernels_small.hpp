@@ -1,0 +1,35 @@
+// kernels_small.hpp -- launchers of the non-GEMM kernels (kernels_small.hip, kernels_vq.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace mvq {
+
+struct DirectConvArgs {
+    const float* x; const float* wp; const float* bias; const float* alpha_in; const float* residual;
+    const float* alpha_out; float* y;
+    int B, Cin, Tin, Cout, Tout, ks, stride, dil, pad, Mpad, act;
+};
+
+hipError_t launch_weight_norm(const float* v, const float* g, float* w, int rows, int inner, hipStream_t s);
+hipError_t launch_pack_conv1d(const float* w, float* wp, int cin, int cout, int ks, int mpad, hipStream_t s);
+hipError_t launch_pack_convtr(const float* w, float* wp, int cin, int cout, int S, int mpad, hipStream_t s);
+hipError_t launch_conv1d_direct(const DirectConvArgs& a, hipStream_t s);
+hipError_t launch_convtr_direct(const DirectConvArgs& a, hipStream_t s);
+hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamma, const float* beta, float* y,
+                              int B, int C, int T, float eps, int do_tanh, float post_scale, hipStream_t s);
+hipError_t launch_attention(const float* q, const float* k, const float* v, float* ctx,
+                            int B, int H, int dh, int Tq, int Tk, hipStream_t s);
+hipError_t launch_gelu(const float* x, float* y, size_t n, hipStream_t s);
+hipError_t launch_rows(const float* a, size_t a_pitch, const float* b, size_t b_pitch, float* y, size_t y_pitch,
+                       size_t rows, int T, hipStream_t s);
+
+hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_out, int32_t* idx_out,
+                                  int B, int D, int T, int nb, int K, int update_residual, hipStream_t s);
+hipError_t launch_ema_update(const float* z, const int32_t* idx, float* books, int B, int D, int T, int nb, int K,
+                             float decay, hipStream_t s);
+hipError_t launch_dac_rvq(const float* z, const float* in_w, const float* in_b, const float* cb, const float* out_w,
+                          const float* out_b, float* zq, int32_t* codes, float* latents,
+                          int B, int C, int T, int nq, int K, int Dc, hipStream_t s);
+}  // namespace mvq

@@ -1,0 +1,348 @@
+// kernels_vq.hip -- codebook searches of the path.
+//
+//  (1) rvq_ema_forward: the reference's own ResidualVQEMA (K <= 512, D = 96): argmax_k(res.e_k - 0.5||e_k||^2)
+//      per book with the residual carried between books.  One block owns TOKS tokens for ALL books; per book the
+//      codebook is pinned in LDS (transposed [D][K] image, at most 256 codes at a time = 96 KiB for D = 96), every
+//      lane scores its own codes for 4 tokens at once and the per-token winner is a wavefront arg-max reduction
+//      (lowest index on ties, like torch.argmax on CPU).
+//  (2) rvq_assign / ema_update: ResidualVQEMA.ema_step (deterministic token-order sums).
+//  (3) dac_rvq: the 32-stage DAC residual quantiser (K = 1024, Dc = 8) fused into ONE launch: in_proj, L2
+//      normalisation, cosine search against the LDS-resident normalised codebook, straight-through out_proj
+//      and residual update, all stages for a block's 16 tokens without leaving the CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "det_math.hpp"
+#include "kernels_small.hpp"
+
+namespace mvq {
+
+// arg-max combine: keep the larger score, the lower index on ties
+__device__ __forceinline__ void amax_combine(float& s, int& i, float os, int oi)
+{
+    if (os > s || (os == s && oi < i)) { s = os; i = oi; }
+}
+
+__device__ __forceinline__ void wave_argmax(float& s, int& i)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float os = __shfl_xor(s, off);
+        const int oi = __shfl_xor(i, off);
+        amax_combine(s, i, os, oi);
+    }
+}
+
+constexpr int RVQ_TOKS = 32;     // tokens per block
+constexpr int RVQ_KH = 256;      // codes resident in LDS at a time
+
+// LDS: Et[D][KH+1] | hn[KH] | resT[D][TOKS] | qsT[D][TOKS] | best_s[TOKS] | best_i[TOKS]
+__global__ __launch_bounds__(256) void rvq_ema_forward_kernel(
+    const float* __restrict__ z, const float* __restrict__ books, float* __restrict__ q_out,
+    int32_t* __restrict__ idx_out, int B, int D, int T, int nb, int K, int update_residual)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int KHP = RVQ_KH + 1;
+    float* Et = sm;
+    float* hn = Et + (size_t)D * KHP;
+    float* resT = hn + RVQ_KH;
+    float* qsT = resT + (size_t)D * RVQ_TOKS;
+    float* best_s = qsT + (size_t)D * RVQ_TOKS;
+    int* best_i = reinterpret_cast<int*>(best_s + RVQ_TOKS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = B * T;
+    const int n0 = blockIdx.x * RVQ_TOKS;
+
+    // load this block's tokens: resT[d][tok]
+    for (int i = tid; i < D * RVQ_TOKS; i += 256) {
+        const int tok = i % RVQ_TOKS, d = i / RVQ_TOKS;
+        const int n = n0 + tok;
+        float v = 0.0f;
+        if (n < N) { const int b = n / T, t = n - b * T; v = z[((size_t)b * D + d) * T + t]; }
+        resT[d * RVQ_TOKS + tok] = v;
+        qsT[d * RVQ_TOKS + tok] = 0.0f;
+    }
+
+    for (int bk = 0; bk < nb; ++bk) {
+        const float* emb = books + (size_t)bk * K * D;
+        for (int k0 = 0; k0 < K; k0 += RVQ_KH) {
+            const int kh = K - k0 < RVQ_KH ? K - k0 : RVQ_KH;
+            __syncthreads();
+            // stage transposed codebook slice: global row-major (coalesced) -> Et[d][k] (odd pitch: conflict-free)
+            for (int i = tid; i < kh * D; i += 256) {
+                const int k = i / D, d = i - k * D;
+                Et[d * KHP + k] = emb[(size_t)(k0 + k) * D + d];
+            }
+            __syncthreads();
+            for (int k = tid; k < kh; k += 256) {
+                float s = 0.0f;
+                for (int d = 0; d < D; ++d) { const float e = Et[d * KHP + k]; s = dfma(e, e, s); }
+                hn[k] = 0.5f * s;
+            }
+            __syncthreads();
+            // each wave scores 8 tokens, 4 at a time
+            for (int g = 0; g < RVQ_TOKS / 4 / 4; ++g) {
+                const int tok0 = wave * (RVQ_TOKS / 4) + g * 4;
+                float bs[4]; int bi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { bs[u] = -__builtin_inff(); bi[u] = 0x7fffffff; }
+                for (int kk = lane; kk < kh; kk += 64) {
+                    float dot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int d = 0; d < D; ++d) {
+                        const float e = Et[d * KHP + kk];
+                        const float4 r = *reinterpret_cast<const float4*>(resT + d * RVQ_TOKS + tok0);
+                        dot[0] = dfma(r.x, e, dot[0]);
+                        dot[1] = dfma(r.y, e, dot[1]);
+                        dot[2] = dfma(r.z, e, dot[2]);
+                        dot[3] = dfma(r.w, e, dot[3]);
+                    }
+                    const float h = hn[kk];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float sc = dot[u] - h;
+                        if (sc > bs[u]) { bs[u] = sc; bi[u] = k0 + kk; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    wave_argmax(bs[u], bi[u]);
+                    if (lane == 0) {
+                        if (k0 == 0) { best_s[tok0 + u] = bs[u]; best_i[tok0 + u] = bi[u]; }
+                        else {
+                            float cs = best_s[tok0 + u]; int ci = best_i[tok0 + u];
+                            amax_combine(cs, ci, bs[u], bi[u]);
+                            best_s[tok0 + u] = cs; best_i[tok0 + u] = ci;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // gather + straight-through sum + residual update (reads the row-major global book: contiguous row)
+        for (int i = tid; i < D * RVQ_TOKS; i += 256) {
+            const int d = i % D, tok = i / D;
+            int id = best_i[tok];
+            if (id < 0 || id >= K) id = 0;                       // all-NaN scores: defined, in-range gather
+            const float q = emb[(size_t)id * D + d];
+            const float r = resT[d * RVQ_TOKS + tok];
+            const float qs = qsT[d * RVQ_TOKS + tok];
+            qsT[d * RVQ_TOKS + tok] = (qs + (q - r)) + r;
+            if (update_residual) resT[d * RVQ_TOKS + tok] = r - q;
+        }
+        if (idx_out && tid < RVQ_TOKS && n0 + tid < N) {
+            int id = best_i[tid];
+            if (id < 0 || id >= K) id = 0;
+            idx_out[(size_t)bk * N + n0 + tid] = id;
+        }
+    }
+    __syncthreads();
+    if (q_out) {
+        for (int i = tid; i < D * RVQ_TOKS; i += 256) {
+            const int tok = i % RVQ_TOKS, d = i / RVQ_TOKS;
+            const int n = n0 + tok;
+            if (n < N) { const int b = n / T, t = n - b * T; q_out[((size_t)b * D + d) * T + t] = qsT[d * RVQ_TOKS + tok]; }
+        }
+    }
+}
+
+hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_out, int32_t* idx_out,
+                                  int B, int D, int T, int nb, int K, int update_residual, hipStream_t s)
+{
+    const int N = B * T;
+    if (N == 0) return hipSuccess;
+    const size_t lds = ((size_t)D * (RVQ_KH + 1) + RVQ_KH + 2 * (size_t)D * RVQ_TOKS + 2 * RVQ_TOKS) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_ema_forward_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(rvq_ema_forward_kernel, dim3((N + RVQ_TOKS - 1) / RVQ_TOKS), dim3(256), lds, s,
+                       z, books, q_out, idx_out, B, D, T, nb, K, update_residual);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// EMA update: thread per (k, d) walks the tokens in order (deterministic sums, = index_add_ order)
+// idx[bk][N] from rvq_ema_forward_kernel(update_residual = 0)
+// ------------------------------------------------------------------------------------------------
+__global__ void ema_update_kernel(const float* __restrict__ z, const int32_t* __restrict__ idx,
+                                  float* __restrict__ books, int B, int D, int T, int K, float decay, float omd)
+{
+    const int bk = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= K * D) return;
+    const int k = e / D, d = e - k * D;
+    const int N = B * T;
+    const int32_t* id = idx + (size_t)bk * N;
+    float sum = 0.0f, cnt = 0.0f;
+    for (int n = 0; n < N; ++n) {
+        if (id[n] == k) {
+            const int b = n / T, t = n - b * T;
+            sum = sum + z[((size_t)b * D + d) * T + t];
+            cnt = cnt + 1.0f;
+        }
+    }
+    if (cnt > 0.0f) {
+        float* p = books + ((size_t)bk * K + k) * D + d;
+        const float mean = sum / (cnt + 1e-9f);
+        *p = decay * (*p) + omd * mean;
+    }
+}
+
+hipError_t launch_ema_update(const float* z, const int32_t* idx, float* books, int B, int D, int T, int nb, int K,
+                             float decay, hipStream_t s)
+{
+    const float omd = (float)(1.0 - (double)decay);
+    hipLaunchKernelGGL(ema_update_kernel, dim3((K * D + 255) / 256, nb), dim3(256), 0, s, z, idx, books, B, D, T, K,
+                       decay, omd);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// DAC residual VQ, all stages fused.  Block = 256 threads, 16 tokens.
+//   LDS: res[C][16] | cbn[K][Dc] | cn2[K] | ze[Dc][16] | e[Dc][16] | pre[Dc][16] | red_s[16][16] | red_i[16][16]
+// ------------------------------------------------------------------------------------------------
+constexpr int DQ_TOK = 16;
+
+__global__ __launch_bounds__(256) void dac_rvq_kernel(
+    const float* __restrict__ z, const float* __restrict__ in_w, const float* __restrict__ in_b,
+    const float* __restrict__ cb, const float* __restrict__ out_w, const float* __restrict__ out_b,
+    float* __restrict__ zq, int32_t* __restrict__ codes, float* __restrict__ latents,
+    int B, int C, int T, int nq, int K, int Dc)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* res = sm;                                   // [C][16]
+    float* cbn = res + (size_t)C * DQ_TOK;             // [K][Dc]
+    float* cn2 = cbn + (size_t)K * Dc;                 // [K]
+    float* ze = cn2 + K;                               // [Dc][16]
+    float* en = ze + Dc * DQ_TOK;                      // [Dc][16]
+    float* pre = en + Dc * DQ_TOK;                     // [Dc][16]
+    float* en2 = pre + Dc * DQ_TOK;                    // [16]
+    float* red_s = en2 + DQ_TOK;                       // [16 groups][16 tok]
+    int* red_i = reinterpret_cast<int*>(red_s + 16 * DQ_TOK);
+
+    const int tid = threadIdx.x;
+    const int tok = tid & 15;
+    const int grp = tid >> 4;                          // 0..15
+    const int N = B * T;
+    const int n0 = blockIdx.x * DQ_TOK;
+    const int n = n0 + tok;
+    const bool live = n < N;
+    const int bb = live ? n / T : 0, tt = live ? n - bb * T : 0;
+
+    const int CPT = C / 16;                            // channels per thread (c = grp + 16*j)
+    float acc[64];                                     // C <= 1024
+#pragma unroll
+    for (int j = 0; j < 64; ++j) acc[j] = 0.0f;
+
+    for (int j = 0; j < CPT; ++j) {
+        const int c = grp + 16 * j;
+        res[c * DQ_TOK + tok] = live ? z[((size_t)bb * C + c) * T + tt] : 0.0f;
+    }
+
+    for (int st = 0; st < nq; ++st) {
+        __syncthreads();
+        // normalised codebook of this stage
+        const float* cbs = cb + (size_t)st * K * Dc;
+        for (int k = tid; k < K; k += 256) {
+            float ss = 0.0f;
+            for (int d = 0; d < Dc; ++d) { const float v = cbs[(size_t)k * Dc + d]; ss = dfma(v, v, ss); }
+            const float den = __builtin_fmaxf(__builtin_sqrtf(ss), 1e-12f);
+            float s2 = 0.0f;
+            for (int d = 0; d < Dc; ++d) { const float v = cbs[(size_t)k * Dc + d] / den; cbn[k * Dc + d] = v; s2 = dfma(v, v, s2); }
+            cn2[k] = s2;
+        }
+        // in_proj: thread (d = grp < Dc, tok): chain over C
+        if (grp < Dc) {
+            const float* wr = in_w + ((size_t)st * Dc + grp) * C;
+            float a = 0.0f;
+            for (int c = 0; c < C; ++c) a = dfma(wr[c], res[c * DQ_TOK + tok], a);
+            const float v = a + in_b[(size_t)st * Dc + grp];
+            ze[grp * DQ_TOK + tok] = v;
+            if (live) latents[((size_t)bb * nq * Dc + (size_t)st * Dc + grp) * T + tt] = v;
+        }
+        __syncthreads();
+        // F.normalize over Dc (every thread of a token computes the same values; grp 0 publishes)
+        {
+            float ss = 0.0f;
+            for (int d = 0; d < Dc; ++d) { const float v = ze[d * DQ_TOK + tok]; ss = dfma(v, v, ss); }
+            const float den = __builtin_fmaxf(__builtin_sqrtf(ss), 1e-12f);
+            float s2 = 0.0f;
+            float ev[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) if (d < Dc) { ev[d] = ze[d * DQ_TOK + tok] / den; s2 = dfma(ev[d], ev[d], s2); }
+            // search: this thread scans codes k = grp + 16*j
+            float bs = -__builtin_inff(); int bi = 0x7fffffff;
+            for (int k = grp; k < K; k += 16) {
+                const float* ck = cbn + k * Dc;
+                float dot = 0.0f;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) if (d < Dc) dot = dfma(ev[d], ck[d], dot);
+                const float dist = (s2 - 2.0f * dot) + cn2[k];
+                const float sc = -dist;
+                if (sc > bs) { bs = sc; bi = k; }
+            }
+            red_s[grp * DQ_TOK + tok] = bs;
+            red_i[grp * DQ_TOK + tok] = bi;
+        }
+        __syncthreads();
+        if (grp == 0) {
+            float bs = red_s[tok]; int bi = red_i[tok];
+            for (int g = 1; g < 16; ++g) amax_combine(bs, bi, red_s[g * DQ_TOK + tok], red_i[g * DQ_TOK + tok]);
+            if (bi < 0 || bi >= K) bi = 0;
+            if (live) codes[((size_t)bb * nq + st) * T + tt] = bi;
+            const float* raw = cbs + (size_t)bi * Dc;
+            for (int d = 0; d < Dc; ++d) { const float zv = ze[d * DQ_TOK + tok]; pre[d * DQ_TOK + tok] = zv + (raw[d] - zv); }
+        }
+        __syncthreads();
+        // out_proj + accumulate + residual update: thread owns channels c = grp + 16*j of its token
+        {
+            float pv[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) if (d < Dc) pv[d] = pre[d * DQ_TOK + tok];
+            const float* ow = out_w + (size_t)st * C * Dc;
+            const float* ob = out_b + (size_t)st * C;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                if (j < CPT) {
+                    const int c = grp + 16 * j;
+                    const float* wr = ow + (size_t)c * Dc;
+                    float a = 0.0f;
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) if (d < Dc) a = dfma(wr[d], pv[d], a);
+                    const float zqi = a + ob[c];
+                    acc[j] = acc[j] + zqi;
+                    res[c * DQ_TOK + tok] = res[c * DQ_TOK + tok] - zqi;
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j)
+            if (j < CPT) zq[((size_t)bb * C + grp + 16 * j) * T + tt] = acc[j];
+    }
+}
+
+hipError_t launch_dac_rvq(const float* z, const float* in_w, const float* in_b, const float* cb, const float* out_w,
+                          const float* out_b, float* zq, int32_t* codes, float* latents,
+                          int B, int C, int T, int nq, int K, int Dc, hipStream_t s)
+{
+    const int N = B * T;
+    if (N == 0) return hipSuccess;
+    const size_t lds = ((size_t)C * DQ_TOK + (size_t)K * Dc + K + 3 * (size_t)Dc * DQ_TOK + DQ_TOK + 2 * 16 * DQ_TOK) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dac_rvq_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(dac_rvq_kernel, dim3((N + DQ_TOK - 1) / DQ_TOK), dim3(256), lds, s,
+                       z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, B, C, T, nq, K, Dc);
+    return hipGetLastError();
+}
+
+}  // namespace mvq

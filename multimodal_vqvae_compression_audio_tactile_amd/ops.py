@@ -1,0 +1,200 @@
+"""Tensor-level wrappers over the C ABI (include/mvq.h).
+
+torch is plumbing here: device memory (caching allocator), the current HIP stream and nothing else.
+Every op takes fp32 tensors on a HIP device, launches on ``torch.cuda.current_stream()`` and returns
+freshly allocated outputs.  Inputs arriving in another dtype (e.g. fp16 under the reference's CUDA AMP
+autocast, Evaluation/compare_dacvsproposal_5_eval.py:441) are widened to fp32: the path computes in fp32.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import MvqError, check
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if t.device.type != "cuda":
+        raise MvqError(f"{name}: tensor is on {t.device}; the MI355X path has no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def conv1d_out_len(tin, ks, stride=1, dil=1, pad=0):
+    span = tin + 2 * pad - dil * (ks - 1) - 1
+    return 0 if span < 0 else span // stride + 1
+
+
+def weight_norm(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """w = v * (g / ||v||) over dim 0 rows (old-style torch weight_norm fold)."""
+    v = _dev(v, "v"); g = _dev(g, "g")
+    w = torch.empty_like(v)
+    rows = v.shape[0]
+    check(_lib.lib().mvq_weight_norm_f32(v.data_ptr(), g.data_ptr(), w.data_ptr(), rows, v.numel() // rows, _stream()),
+          "mvq_weight_norm_f32")
+    return w
+
+
+def pack_conv1d(w: torch.Tensor) -> torch.Tensor:
+    """torch layout w[Cout, Cin, ks] -> K-major packed image used by conv1d()."""
+    w = _dev(w, "w")
+    cout, cin, ks = w.shape
+    n = _lib.lib().mvq_conv1d_packed_floats(cin, cout, ks)
+    wp = torch.empty(n, device=w.device, dtype=torch.float32)
+    check(_lib.lib().mvq_conv1d_pack_f32(w.data_ptr(), wp.data_ptr(), cin, cout, ks, _stream()), "mvq_conv1d_pack_f32")
+    return wp
+
+
+def pack_conv_transpose1d(w: torch.Tensor, stride: int) -> torch.Tensor:
+    """torch layout w[Cin, Cout, 2*stride] -> polyphase packed image used by conv_transpose1d()."""
+    w = _dev(w, "w")
+    cin, cout, ks = w.shape
+    if ks != 2 * stride:
+        raise MvqError(f"conv_transpose1d: kernel {ks} != 2*stride ({stride}) is outside the path")
+    n = _lib.lib().mvq_conv_transpose1d_packed_floats(cin, cout, stride)
+    wp = torch.empty(n, device=w.device, dtype=torch.float32)
+    check(_lib.lib().mvq_conv_transpose1d_pack_f32(w.data_ptr(), wp.data_ptr(), cin, cout, stride, _stream()),
+          "mvq_conv_transpose1d_pack_f32")
+    return wp
+
+
+def conv1d(x, wp, cout, ks, bias=None, stride=1, dil=1, pad=0, alpha_in=None, residual=None, alpha_out=None,
+           tanh=False, out=None):
+    x = _dev(x, "x")
+    B, cin, tin = x.shape
+    tout = conv1d_out_len(tin, ks, stride, dil, pad)
+    if out is None:
+        out = torch.empty(B, cout, tout, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        residual = _dev(residual, "residual")
+        if tuple(residual.shape) != (B, cout, tout):
+            raise MvqError(f"conv1d: residual shape {tuple(residual.shape)} != {(B, cout, tout)}")
+    check(_lib.lib().mvq_conv1d_f32(x.data_ptr(), wp.data_ptr(), _p(bias), _p(alpha_in), _p(residual), _p(alpha_out),
+                                    out.data_ptr(), B, cin, tin, cout, ks, stride, dil, pad, 1 if tanh else 0,
+                                    _stream()), "mvq_conv1d_f32")
+    return out
+
+
+def conv_transpose1d(x, wp, cout, stride, pad, bias=None, alpha_in=None, alpha_out=None):
+    x = _dev(x, "x")
+    B, cin, tin = x.shape
+    tout = (tin - 1) * stride - 2 * pad + 2 * stride
+    out = torch.empty(B, cout, max(tout, 0), device=x.device, dtype=torch.float32)
+    check(_lib.lib().mvq_conv_transpose1d_f32(x.data_ptr(), wp.data_ptr(), _p(bias), _p(alpha_in), _p(alpha_out),
+                                              out.data_ptr(), B, cin, tin, cout, stride, pad, _stream()),
+          "mvq_conv_transpose1d_f32")
+    return out
+
+
+def rvq_ema_forward(z, books, n_books_use=None, return_indices=False):
+    """ResidualVQEMA.forward.  z[B,D,T]; books[nb,K,D] (stacked).  -> q[B,D,T] (, idx[nb_use, B*T] int64)."""
+    z = _dev(z, "z"); books = _dev(books, "books")
+    B, D, T = z.shape
+    nb_all, K, D2 = books.shape
+    if D2 != D:
+        raise MvqError(f"rvq: book dim {D2} != token dim {D}")
+    nb = nb_all if n_books_use is None else max(0, min(int(n_books_use), nb_all))
+    q = torch.empty_like(z)
+    idx = torch.empty(nb, B * T, device=z.device, dtype=torch.int32) if return_indices else None
+    check(_lib.lib().mvq_rvq_ema_forward_f32(z.data_ptr(), books.data_ptr(), q.data_ptr(), _p(idx), B, D, T, nb, K,
+                                             _stream()), "mvq_rvq_ema_forward_f32")
+    if return_indices:
+        return q, idx.long()
+    return q
+
+
+def rvq_ema_step_(z_tokens, books, decay=0.99):
+    """ResidualVQEMA.ema_step: updates `books` [nb,K,D] in place."""
+    z = _dev(z_tokens, "z_tokens")
+    if books.device.type != "cuda" or books.dtype != torch.float32 or not books.is_contiguous():
+        raise MvqError("rvq_ema_step_: books must be a contiguous fp32 HIP tensor (updated in place)")
+    B, D, T = z.shape
+    nb, K, _ = books.shape
+    nbytes = _lib.lib().mvq_rvq_ema_step_scratch_bytes(B, T, nb, K, D)
+    scratch = torch.empty(max(nbytes, 4), device=z.device, dtype=torch.uint8)
+    check(_lib.lib().mvq_rvq_ema_step_f32(z.data_ptr(), books.data_ptr(), scratch.data_ptr(), B, D, T, nb, K,
+                                          float(decay), _stream()), "mvq_rvq_ema_step_f32")
+    return books
+
+
+def dac_rvq(z, in_w, in_b, codebook, out_w, out_b, n_q):
+    """DAC ResidualVectorQuantize (eval) -> (z_q, codes int64 [B,nq,T], latents [B,nq*Dc,T])."""
+    z = _dev(z, "z")
+    B, C, T = z.shape
+    _, K, Dc = codebook.shape
+    zq = torch.empty_like(z)
+    codes = torch.empty(B, n_q, T, device=z.device, dtype=torch.int32)
+    lat = torch.empty(B, n_q * Dc, T, device=z.device, dtype=torch.float32)
+    check(_lib.lib().mvq_dac_rvq_f32(z.data_ptr(), in_w.data_ptr(), in_b.data_ptr(), codebook.data_ptr(),
+                                     out_w.data_ptr(), out_b.data_ptr(), zq.data_ptr(), codes.data_ptr(),
+                                     lat.data_ptr(), B, C, T, n_q, K, Dc, _stream()), "mvq_dac_rvq_f32")
+    return zq, codes.long(), lat
+
+
+def layernorm_c(x, gamma, beta, pe=None, eps=1e-5, do_tanh=False, post_scale=1.0):
+    x = _dev(x, "x")
+    B, C, T = x.shape
+    y = torch.empty_like(x)
+    if pe is not None and (pe.shape[0] < T or pe.shape[1] != C):
+        raise MvqError(f"layernorm_c: pe table {tuple(pe.shape)} too small for T={T}, C={C}")
+    check(_lib.lib().mvq_layernorm_c_f32(x.data_ptr(), _p(pe), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                         B, C, T, float(eps), int(do_tanh), float(post_scale), _stream()),
+          "mvq_layernorm_c_f32")
+    return y
+
+
+def attention(q, k, v, heads):
+    q = _dev(q, "q"); k = _dev(k, "k"); v = _dev(v, "v")
+    B, C, Tq = q.shape
+    Tk = k.shape[2]
+    ctx = torch.empty_like(q)
+    check(_lib.lib().mvq_attention_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), ctx.data_ptr(), B, heads, C // heads,
+                                       Tq, Tk, _stream()), "mvq_attention_f32")
+    return ctx
+
+
+def gelu(x):
+    x = _dev(x, "x")
+    y = torch.empty_like(x)
+    check(_lib.lib().mvq_gelu_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "mvq_gelu_f32")
+    return y
+
+
+def sub_time_slice(a, s, e, b):
+    """a[..., s:e] - b for a[B,C,T], b[B,C,e-s] without materialising the slice."""
+    a = _dev(a, "a"); b = _dev(b, "b")
+    B, C, T = a.shape
+    n = e - s
+    y = torch.empty(B, C, n, device=a.device, dtype=torch.float32)
+    check(_lib.lib().mvq_sub_rows_f32(a.data_ptr() + 4 * s, T, b.data_ptr(), n, y.data_ptr(), n, B * C, n, _stream()),
+          "mvq_sub_rows_f32")
+    return y
+
+
+def copy_time_slice(a, s, e):
+    a = _dev(a, "a")
+    B, C, T = a.shape
+    n = e - s
+    y = torch.empty(B, C, n, device=a.device, dtype=torch.float32)
+    check(_lib.lib().mvq_copy_rows_f32(a.data_ptr() + 4 * s, T, y.data_ptr(), n, B * C, n, _stream()), "mvq_copy_rows_f32")
+    return y
+
+
+def write_time_slice_(dst, s, src):
+    """dst[..., s:s+n] = src for dst[B,C,T], src[B,C,n]."""
+    B, C, T = dst.shape
+    n = src.shape[2]
+    check(_lib.lib().mvq_copy_rows_f32(src.data_ptr(), n, dst.data_ptr() + 4 * s, T, B * C, n, _stream()),
+          "mvq_copy_rows_f32")
+    return dst
