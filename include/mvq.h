@@ -89,8 +89,8 @@ int mvq_rvq_ema_forward_f32(const float* z, const float* books, float* q_out, in
 
 /* ResidualVQEMA.ema_step (Training/compare_dacvsproposal_5.py:266-277): every book matched against the
  * SAME tokens X = z_tokens[B,D,T]; used codes move to decay*e + (1-decay)*mean(assigned tokens).
- * books[nb,K,D] updated in place.  scratch: >= nb*(K*D + K) floats + nb*B*T int32 (see
- * mvq_rvq_ema_step_scratch_bytes).  Sums are accumulated in token order (deterministic). */
+ * books[nb,K,D] updated in place.  scratch: mvq_rvq_ema_step_scratch_bytes() bytes (the per-book
+ * assignments, nb*B*T int32).  Sums are accumulated in token order (deterministic, = index_add_ order). */
 size_t mvq_rvq_ema_step_scratch_bytes(int batch, int t, int nb, int k, int dim);
 int mvq_rvq_ema_step_f32(const float* z_tokens, float* books, void* scratch,
                          int batch, int dim, int t, int nb, int k, float decay, void* stream);
@@ -106,27 +106,35 @@ int mvq_dac_rvq_f32(const float* z, const float* in_w, const float* in_b, const 
 
 /* ---- predictor / glue primitives (CrossPredictor, TokenNorm, PosEnc1D) --------------------------- */
 
-/* y = post_scale * tanh?( LayerNorm_C(x + pe?) ) on channel-major x[B,C,T] (normalise over C, eps, biased
- * variance).  pe[max_len, C] (row = position) or NULL; positions are 0..T-1 (PosEnc1D restarts per call).
+/* y = post_scale * tanh?( LayerNorm_C(x + pe?) ), normalising over the channel axis (eps, biased variance).
+ * Element (b, c, t) of x and y lives at  b*stride_b + c*stride_c + t ; pass stride_b = stride_c = 0 for a
+ * contiguous [B,C,T] tensor.  (The AR loop keeps chunk tensors token-folded as [C, B*Tc]: stride_b = Tc,
+ * stride_c = B*Tc, so that the predictor GEMMs see N = B*Tc contiguous columns.)
+ * pe[max_len, C] (row = position) or NULL; positions are 0..T-1 (PosEnc1D restarts per call).
  * Replaces PosEnc1D + ln_q/ln_kv/ffn[0] (Training/compare_dacvsproposal_5.py:236-238,243) and
  * torch.tanh(TokenNorm(r)) * scale (...:313-315). */
 int mvq_layernorm_c_f32(const float* x, const float* pe, const float* gamma, const float* beta, float* y,
-                        int batch, int c, int t, float eps, int do_tanh, float post_scale, void* stream);
+                        int batch, int c, int t, size_t stride_b, size_t stride_c,
+                        float eps, int do_tanh, float post_scale, void* stream);
 
-/* softmax(Q K^T / sqrt(dh)) V per head on channel-major Q[B,C,Tq], K,V[B,C,Tk] -> ctx[B,C,Tq]
- * (Training/compare_dacvsproposal_5.py:239-242).  Tk may be 0 (ctx = 0).  Tk <= 64. */
+/* softmax(Q K^T / sqrt(dh)) V per head (Training/compare_dacvsproposal_5.py:239-242).  Q, ctx: (b,c,i) at
+ * b*q_stride_b + c*q_stride_c + i ; K, V: (b,c,j) at b*k_stride_b + c*k_stride_c + j (0,0 = contiguous).
+ * Tk may be 0 (ctx = 0).  Tk <= 64. */
 int mvq_attention_f32(const float* q, const float* k, const float* v, float* ctx,
-                      int batch, int heads, int dh, int tq, int tk, void* stream);
+                      int batch, int heads, int dh, int tq, int tk,
+                      size_t q_stride_b, size_t q_stride_c, size_t k_stride_b, size_t k_stride_c, void* stream);
 
 /* y = gelu_erf(x) elementwise (nn.GELU() in CrossPredictor.ffn). */
 int mvq_gelu_f32(const float* x, float* y, size_t n, void* stream);
 
-/* y = a - b elementwise (r = zt[..., s:e] - z_pred) on strided [B,C,T] views:
- * a has time stride 1 and row pitch a_pitch (elements), rows = B*C. */
-int mvq_sub_rows_f32(const float* a, size_t a_pitch, const float* b, size_t b_pitch, float* y, size_t y_pitch,
-                     size_t rows, int t, void* stream);
-/* copy rows (strided) : y[r, :t] = a[r, :t] */
-int mvq_copy_rows_f32(const float* a, size_t a_pitch, float* y, size_t y_pitch, size_t rows, int t, void* stream);
+/* y(b,c,t) = a(b,c,t) - b(b,c,t)   and   y(b,c,t) = a(b,c,t)   on [batch, c, n] views, each tensor with its
+ * own (batch, channel) element strides and time stride 1: chunk slicing `zt[..., s:e] - z_pred`,
+ * `z_run[..., s:e] = z_hat` (Training/compare_dacvsproposal_5.py:312,319) and the fold/unfold between
+ * [B,C,T] and the token-folded [C, B*n] chunk layout. */
+int mvq_sub3d_f32(const float* a, size_t a_sb, size_t a_sc, const float* b, size_t b_sb, size_t b_sc,
+                  float* y, size_t y_sb, size_t y_sc, int batch, int c, int n, void* stream);
+int mvq_copy3d_f32(const float* a, size_t a_sb, size_t a_sc, float* y, size_t y_sb, size_t y_sc,
+                   int batch, int c, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -83,12 +83,12 @@ int mvq_conv1d_f32(const float* x, const float* wp, const float* bias, const flo
                    const float* residual, const float* alpha_out, float* y,
                    int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act, void* stream)
 {
-    if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv1d: null tensor");
     if (batch < 0 || cin <= 0 || cout <= 0 || tin < 0 || ks <= 0 || stride <= 0 || dil <= 0 || pad < 0)
         return fail(MVQ_EINVAL, "conv1d: bad shape B=%d Cin=%d Tin=%d Cout=%d ks=%d s=%d d=%d p=%d", batch, cin, tin, cout, ks, stride, dil, pad);
     if (act != MVQ_ACT_NONE && act != MVQ_ACT_TANH) return fail(MVQ_EINVAL, "conv1d: bad act %d", act);
     const int tout = conv_out_len(tin, ks, stride, dil, pad);
     if (batch == 0 || tout == 0) return MVQ_OK;
+    if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv1d: null tensor");
     const int mpad = mvq::conv_mpad(cout);
     const int bm = mvq::conv_tile_bm(cout);
 
@@ -144,9 +144,10 @@ int mvq_conv_transpose1d_f32(const float* x, const float* wp, const float* bias,
 int mvq_rvq_ema_forward_f32(const float* z, const float* books, float* q_out, int32_t* idx_out,
                             int batch, int dim, int t, int nb_use, int k, void* stream)
 {
-    if (!z || !q_out || (nb_use > 0 && !books)) return fail(MVQ_EINVAL, "rvq_ema_forward: null tensor");
-    if (batch < 0 || t < 0 || dim <= 0 || dim > 128 || nb_use < 0 || k <= 0)
+    if (batch < 0 || t < 0 || dim <= 0 || dim > 128 || dim % 4 != 0 || nb_use < 0 || k <= 0)
         return fail(MVQ_EINVAL, "rvq_ema_forward: bad shape B=%d D=%d T=%d nb=%d K=%d", batch, dim, t, nb_use, k);
+    if (batch == 0 || t == 0) return MVQ_OK;
+    if (!z || !q_out || (nb_use > 0 && !books)) return fail(MVQ_EINVAL, "rvq_ema_forward: null tensor");
     hipError_t e = mvq::launch_rvq_ema_forward(z, books, q_out, idx_out, batch, dim, t, nb_use, k, 1, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "rvq_ema_forward");
 }
@@ -161,7 +162,7 @@ int mvq_rvq_ema_step_f32(const float* z_tokens, float* books, void* scratch,
                          int batch, int dim, int t, int nb, int k, float decay, void* stream)
 {
     if (!z_tokens || !books || !scratch) return fail(MVQ_EINVAL, "rvq_ema_step: null tensor");
-    if (batch < 0 || t < 0 || dim <= 0 || dim > 128 || nb <= 0 || k <= 0) return fail(MVQ_EINVAL, "rvq_ema_step: bad shape");
+    if (batch < 0 || t < 0 || dim <= 0 || dim > 128 || dim % 4 != 0 || nb <= 0 || k <= 0) return fail(MVQ_EINVAL, "rvq_ema_step: bad shape");
     if (batch * t == 0) return MVQ_OK;
     int32_t* idx = reinterpret_cast<int32_t*>(scratch);
     hipError_t e = mvq::launch_rvq_ema_forward(z_tokens, books, nullptr, idx, batch, dim, t, nb, k, 0, S(stream));
@@ -185,19 +186,28 @@ int mvq_dac_rvq_f32(const float* z, const float* in_w, const float* in_b, const 
 }
 
 int mvq_layernorm_c_f32(const float* x, const float* pe, const float* gamma, const float* beta, float* y,
-                        int batch, int c, int t, float eps, int do_tanh, float post_scale, void* stream)
+                        int batch, int c, int t, size_t stride_b, size_t stride_c,
+                        float eps, int do_tanh, float post_scale, void* stream)
 {
-    if (!x || !gamma || !beta || !y || c <= 0 || batch < 0 || t < 0) return fail(MVQ_EINVAL, "layernorm_c: bad argument");
-    hipError_t e = mvq::launch_layernorm_c(x, pe, gamma, beta, y, batch, c, t, eps, do_tanh, post_scale, S(stream));
+    if (c <= 0 || batch < 0 || t < 0) return fail(MVQ_EINVAL, "layernorm_c: bad shape");
+    if (batch == 0 || t == 0) return MVQ_OK;                      /* empty chunk (Tk == 0 at a file end) */
+    if (!x || !gamma || !beta || !y) return fail(MVQ_EINVAL, "layernorm_c: null tensor");
+    if (stride_b == 0 && stride_c == 0) { stride_b = (size_t)c * t; stride_c = (size_t)t; }
+    hipError_t e = mvq::launch_layernorm_c(x, pe, gamma, beta, y, batch, c, t, stride_b, stride_c, eps, do_tanh, post_scale, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "layernorm_c");
 }
 
 int mvq_attention_f32(const float* q, const float* k, const float* v, float* ctx,
-                      int batch, int heads, int dh, int tq, int tk, void* stream)
+                      int batch, int heads, int dh, int tq, int tk,
+                      size_t q_stride_b, size_t q_stride_c, size_t k_stride_b, size_t k_stride_c, void* stream)
 {
-    if (!q || !ctx || (tk > 0 && (!k || !v))) return fail(MVQ_EINVAL, "attention: null tensor");
     if (batch < 0 || heads <= 0 || dh <= 0 || tq < 0 || tk < 0 || tk > 64) return fail(MVQ_EINVAL, "attention: bad shape (Tk <= 64)");
-    hipError_t e = mvq::launch_attention(q, k, v, ctx, batch, heads, dh, tq, tk, S(stream));
+    if (batch == 0 || tq == 0) return MVQ_OK;
+    if (!q || !ctx || (tk > 0 && (!k || !v))) return fail(MVQ_EINVAL, "attention: null tensor");
+    const size_t c = (size_t)heads * dh;
+    if (q_stride_b == 0 && q_stride_c == 0) { q_stride_b = c * tq; q_stride_c = (size_t)tq; }
+    if (k_stride_b == 0 && k_stride_c == 0) { k_stride_b = c * tk; k_stride_c = (size_t)tk; }
+    hipError_t e = mvq::launch_attention(q, k, v, ctx, batch, heads, dh, tq, tk, q_stride_b, q_stride_c, k_stride_b, k_stride_c, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "attention");
 }
 
@@ -208,19 +218,22 @@ int mvq_gelu_f32(const float* x, float* y, size_t n, void* stream)
     return e == hipSuccess ? MVQ_OK : hipfail(e, "gelu");
 }
 
-int mvq_sub_rows_f32(const float* a, size_t a_pitch, const float* b, size_t b_pitch, float* y, size_t y_pitch,
-                     size_t rows, int t, void* stream)
+int mvq_sub3d_f32(const float* a, size_t a_sb, size_t a_sc, const float* b, size_t b_sb, size_t b_sc,
+                  float* y, size_t y_sb, size_t y_sc, int batch, int c, int n, void* stream)
 {
-    if ((!a || !b || !y) && rows && t) return fail(MVQ_EINVAL, "sub_rows: null tensor");
-    hipError_t e = mvq::launch_rows(a, a_pitch, b, b_pitch, y, y_pitch, rows, t, S(stream));
-    return e == hipSuccess ? MVQ_OK : hipfail(e, "sub_rows");
+    if ((!a || !b || !y) && batch && c && n) return fail(MVQ_EINVAL, "sub3d: null tensor");
+    if (batch < 0 || c < 0 || n < 0) return fail(MVQ_EINVAL, "sub3d: bad shape");
+    hipError_t e = mvq::launch_strided3d(a, a_sb, a_sc, b, b_sb, b_sc, y, y_sb, y_sc, batch, c, n, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "sub3d");
 }
 
-int mvq_copy_rows_f32(const float* a, size_t a_pitch, float* y, size_t y_pitch, size_t rows, int t, void* stream)
+int mvq_copy3d_f32(const float* a, size_t a_sb, size_t a_sc, float* y, size_t y_sb, size_t y_sc,
+                   int batch, int c, int n, void* stream)
 {
-    if ((!a || !y) && rows && t) return fail(MVQ_EINVAL, "copy_rows: null tensor");
-    hipError_t e = mvq::launch_rows(a, a_pitch, nullptr, 0, y, y_pitch, rows, t, S(stream));
-    return e == hipSuccess ? MVQ_OK : hipfail(e, "copy_rows");
+    if ((!a || !y) && batch && c && n) return fail(MVQ_EINVAL, "copy3d: null tensor");
+    if (batch < 0 || c < 0 || n < 0) return fail(MVQ_EINVAL, "copy3d: bad shape");
+    hipError_t e = mvq::launch_strided3d(a, a_sb, a_sc, nullptr, 0, 0, y, y_sb, y_sc, batch, c, n, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "copy3d");
 }
 
 }  // extern "C"

@@ -170,47 +170,48 @@ hipError_t launch_convtr_direct(const DirectConvArgs& a, hipStream_t s)
 // ------------------------------------------------------------------------------------------------
 __global__ void layernorm_c_kernel(const float* __restrict__ x, const float* __restrict__ pe,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ y, int B, int C, int T, float eps, int do_tanh,
-                                   float post_scale)
+                                   float* __restrict__ y, int B, int C, int T, size_t sb, size_t sc,
+                                   float eps, int do_tanh, float post_scale)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= B * T) return;
     const int b = n / T, t = n - b * T;
-    const float* xb = x + (size_t)b * C * T + t;
+    const float* xb = x + (size_t)b * sb + t;
     const float* per = pe ? pe + (size_t)t * C : nullptr;
     float s = 0.0f;
     for (int c = 0; c < C; ++c) {
-        float v = xb[(size_t)c * T];
+        float v = xb[(size_t)c * sc];
         if (per) v = v + per[c];
         s = s + v;
     }
     const float mean = s / (float)C;
     float var = 0.0f;
     for (int c = 0; c < C; ++c) {
-        float v = xb[(size_t)c * T];
+        float v = xb[(size_t)c * sc];
         if (per) v = v + per[c];
         const float d = v - mean;
         var = dfma(d, d, var);
     }
     const float rstd = 1.0f / __builtin_sqrtf(var / (float)C + eps);
-    float* yb = y + (size_t)b * C * T + t;
+    float* yb = y + (size_t)b * sb + t;
     for (int c = 0; c < C; ++c) {
-        float v = xb[(size_t)c * T];
+        float v = xb[(size_t)c * sc];
         if (per) v = v + per[c];
         float o = dfma((v - mean) * rstd, gamma[c], beta[c]);
         if (do_tanh) o = det_tanh(o);
         if (do_tanh || post_scale != 1.0f) o = post_scale * o;
-        yb[(size_t)c * T] = o;
+        yb[(size_t)c * sc] = o;
     }
 }
 
 hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamma, const float* beta, float* y,
-                              int B, int C, int T, float eps, int do_tanh, float post_scale, hipStream_t s)
+                              int B, int C, int T, size_t sb, size_t sc, float eps, int do_tanh, float post_scale,
+                              hipStream_t s)
 {
     const int n = B * T;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(layernorm_c_kernel, dim3((n + 63) / 64), dim3(64), 0, s, x, pe, gamma, beta, y, B, C, T, eps,
-                       do_tanh, post_scale);
+    hipLaunchKernelGGL(layernorm_c_kernel, dim3((n + 63) / 64), dim3(64), 0, s, x, pe, gamma, beta, y, B, C, T, sb, sc,
+                       eps, do_tanh, post_scale);
     return hipGetLastError();
 }
 
@@ -219,7 +220,8 @@ hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamm
 // ------------------------------------------------------------------------------------------------
 __global__ void attention_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                  const float* __restrict__ V, float* __restrict__ ctx,
-                                 int B, int H, int dh, int Tq, int Tk)
+                                 int B, int H, int dh, int Tq, int Tk,
+                                 size_t qsb, size_t qsc, size_t ksb, size_t ksc)
 {
     extern __shared__ float pbuf[];                     // [blockDim.x][Tk]
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -227,16 +229,15 @@ __global__ void attention_kernel(const float* __restrict__ Q, const float* __res
     const int i = n % Tq;
     const int bh = n / Tq;
     const int hd = bh % H, b = bh / H;
-    const int C = H * dh;
-    const float* q = Q + ((size_t)b * C + (size_t)hd * dh) * Tq + i;
-    const float* kb = K + ((size_t)b * C + (size_t)hd * dh) * Tk;
-    const float* vb = V + ((size_t)b * C + (size_t)hd * dh) * Tk;
+    const float* q = Q + (size_t)b * qsb + (size_t)hd * dh * qsc + i;
+    const float* kb = K + (size_t)b * ksb + (size_t)hd * dh * ksc;
+    const float* vb = V + (size_t)b * ksb + (size_t)hd * dh * ksc;
     float* p = pbuf + (size_t)threadIdx.x * Tk;
     const float rs = __builtin_sqrtf((float)dh);
     float m = -__builtin_inff();
     for (int j = 0; j < Tk; ++j) {
         float a = 0.0f;
-        for (int d = 0; d < dh; ++d) a = dfma(q[(size_t)d * Tq], kb[(size_t)d * Tk + j], a);
+        for (int d = 0; d < dh; ++d) a = dfma(q[(size_t)d * qsc], kb[(size_t)d * ksc + j], a);
         a = a / rs;
         p[j] = a;
         m = __builtin_fmaxf(m, a);
@@ -244,22 +245,24 @@ __global__ void attention_kernel(const float* __restrict__ Q, const float* __res
     float l = 0.0f;
     for (int j = 0; j < Tk; ++j) { const float e = det_exp(p[j] - m); p[j] = e; l = l + e; }
     for (int j = 0; j < Tk; ++j) p[j] = p[j] / l;
-    float* out = ctx + ((size_t)b * C + (size_t)hd * dh) * Tq + i;
+    float* out = ctx + (size_t)b * qsb + (size_t)hd * dh * qsc + i;
     for (int d = 0; d < dh; ++d) {
         float a = 0.0f;
-        for (int j = 0; j < Tk; ++j) a = dfma(p[j], vb[(size_t)d * Tk + j], a);
-        out[(size_t)d * Tq] = a;
+        for (int j = 0; j < Tk; ++j) a = dfma(p[j], vb[(size_t)d * ksc + j], a);
+        out[(size_t)d * qsc] = a;
     }
 }
 
 hipError_t launch_attention(const float* q, const float* k, const float* v, float* ctx,
-                            int B, int H, int dh, int Tq, int Tk, hipStream_t s)
+                            int B, int H, int dh, int Tq, int Tk, size_t qsb, size_t qsc, size_t ksb, size_t ksc,
+                            hipStream_t s)
 {
     const int n = B * H * Tq;
     if (n == 0) return hipSuccess;
     const int threads = 64;
     hipLaunchKernelGGL(attention_kernel, dim3((n + threads - 1) / threads), dim3(threads),
-                       (size_t)threads * (Tk > 0 ? Tk : 1) * sizeof(float), s, q, k, v, ctx, B, H, dh, Tq, Tk);
+                       (size_t)threads * (Tk > 0 ? Tk : 1) * sizeof(float), s, q, k, v, ctx, B, H, dh, Tq, Tk,
+                       qsb, qsc, ksb, ksc);
     return hipGetLastError();
 }
 
@@ -277,26 +280,31 @@ hipError_t launch_gelu(const float* x, float* y, size_t n, hipStream_t s)
     return hipGetLastError();
 }
 
-__global__ void rows_kernel(const float* __restrict__ a, size_t a_pitch, const float* __restrict__ b, size_t b_pitch,
-                            float* __restrict__ y, size_t y_pitch, size_t rows, int T)
+// y(b,c,t) = a(b,c,t) [- b2(b,c,t)] on [B,C,n] views with per-tensor (batch, channel) strides, time stride 1:
+// slicing chunks out of [B,C,T] tensors and converting to/from the token-folded [C, B*n] layout of the AR loop.
+__global__ void strided3d_kernel(const float* __restrict__ a, size_t asb, size_t asc,
+                                 const float* __restrict__ b2, size_t bsb, size_t bsc,
+                                 float* __restrict__ y, size_t ysb, size_t ysc, int B, int C, int n)
 {
-    const size_t total = rows * (size_t)T;
+    const size_t total = (size_t)B * C * n;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t r = i / T;
-        const int t = (int)(i - r * T);
-        float v = a[r * a_pitch + t];
-        if (b) v = v - b[r * b_pitch + t];
-        y[r * y_pitch + t] = v;
+        const int t = (int)(i % n);
+        const size_t bc = i / n;
+        const int c = (int)(bc % C);
+        const int b = (int)(bc / C);
+        float v = a[(size_t)b * asb + (size_t)c * asc + t];
+        if (b2) v = v - b2[(size_t)b * bsb + (size_t)c * bsc + t];
+        y[(size_t)b * ysb + (size_t)c * ysc + t] = v;
     }
 }
 
-hipError_t launch_rows(const float* a, size_t a_pitch, const float* b, size_t b_pitch, float* y, size_t y_pitch,
-                       size_t rows, int T, hipStream_t s)
+hipError_t launch_strided3d(const float* a, size_t asb, size_t asc, const float* b2, size_t bsb, size_t bsc,
+                            float* y, size_t ysb, size_t ysc, int B, int C, int n, hipStream_t s)
 {
-    const size_t total = rows * (size_t)T;
+    const size_t total = (size_t)B * C * n;
     if (total == 0) return hipSuccess;
     size_t blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, a_pitch, b, b_pitch, y, y_pitch, rows, T);
+    hipLaunchKernelGGL(strided3d_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, asb, asc, b2, bsb, bsc, y, ysb, ysc, B, C, n);
     return hipGetLastError();
 }
 

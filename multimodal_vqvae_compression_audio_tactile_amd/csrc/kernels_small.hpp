@@ -18,12 +18,14 @@ hipError_t launch_pack_convtr(const float* w, float* wp, int cin, int cout, int 
 hipError_t launch_conv1d_direct(const DirectConvArgs& a, hipStream_t s);
 hipError_t launch_convtr_direct(const DirectConvArgs& a, hipStream_t s);
 hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamma, const float* beta, float* y,
-                              int B, int C, int T, float eps, int do_tanh, float post_scale, hipStream_t s);
+                              int B, int C, int T, size_t sb, size_t sc, float eps, int do_tanh, float post_scale,
+                              hipStream_t s);
 hipError_t launch_attention(const float* q, const float* k, const float* v, float* ctx,
-                            int B, int H, int dh, int Tq, int Tk, hipStream_t s);
+                            int B, int H, int dh, int Tq, int Tk, size_t qsb, size_t qsc, size_t ksb, size_t ksc,
+                            hipStream_t s);
 hipError_t launch_gelu(const float* x, float* y, size_t n, hipStream_t s);
-hipError_t launch_rows(const float* a, size_t a_pitch, const float* b, size_t b_pitch, float* y, size_t y_pitch,
-                       size_t rows, int T, hipStream_t s);
+hipError_t launch_strided3d(const float* a, size_t asb, size_t asc, const float* b2, size_t bsb, size_t bsc,
+                            float* y, size_t ysb, size_t ysc, int B, int C, int n, hipStream_t s);
 
 hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_out, int32_t* idx_out,
                                   int B, int D, int T, int nb, int K, int update_residual, hipStream_t s);

@@ -1,0 +1,300 @@
+"""Drop-in for the ``dac.DAC`` (24 kHz) object surface the reference scripts touch, backed by libmvq_hip.so.
+
+What the reference uses:
+  ``dac.DAC.load(path).to(DEVICE).eval()`` then ``.encoder``, ``.quantizer``, ``.decoder`` pulled apart and
+  passed to ``AllPredAR`` / ``ProposedEval`` (Training/compare_dacvsproposal_5.py:329-338,
+  Evaluation/dac_vcpwq_proposed6_latency.py:527-535); ``encoder(x)``, ``quantizer(z)`` -> 5-tuple,
+  ``decoder(z)``, ``mdl.encode(x, n_quantizers=n)``, ``mdl.decode(z)``
+  (Evaluation/compare_dacvsproposal_5_eval.py:369-370).
+
+The modules below are ``torch.nn.Module`` parameter containers with the upstream parameter names
+(``block.{i}...weight_g|weight_v|bias|alpha``, ``model.{i}...``, ``quantizers.{i}.in_proj|out_proj|codebook``)
+so that reference checkpoints (``A_ENC.* / A_QUANT.* / T_ENC.* / T_DEC.*``) load unchanged.  ``forward`` never
+touches torch math: it walks a fused launch plan over the C ABI (weight-norm folded and packed once, Snake1d
+fused into the neighbouring conv's prologue/epilogue, residual adds and tanh fused into epilogues).
+Parameters are frozen by the reference (``requires_grad_(False)``, Training/...5.py:283-284); autograd through
+the decoder input (training config) is not part of this round.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import MvqError
+
+ENC_RATES = (2, 4, 5, 8)
+DEC_RATES = (8, 5, 4, 2)
+
+
+class _Packed:
+    """Cache of derived device tensors keyed on the (identity, version, storage) of their source parameters."""
+
+    def __init__(self):
+        self._key = None
+        self.value = None
+
+    def get(self, params, make):
+        key = tuple((id(p), p._version, p.data_ptr(), str(p.device)) for p in params)
+        if key != self._key:
+            self.value = make()
+            self._key = key
+        return self.value
+
+
+class Snake1d(nn.Module):
+    """Parameter holder for the upstream Snake1d (alpha [1,C,1]); applied fused inside the adjacent conv."""
+
+    def __init__(self, channels: int):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.ones(1, channels, 1))
+
+    def flat(self) -> torch.Tensor:
+        return self.alpha.detach().reshape(-1).float().contiguous()
+
+
+class WNConv1d(nn.Module):
+    """weight_norm(nn.Conv1d) parameter holder (old-style names weight_g / weight_v / bias)."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, dilation=1, padding=0):
+        super().__init__()
+        self.cin, self.cout, self.ks = cin, cout, kernel_size
+        self.stride, self.dilation, self.padding = stride, dilation, padding
+        v = torch.randn(cout, cin, kernel_size) / math.sqrt(cin * kernel_size)
+        self.weight_g = nn.Parameter(v.reshape(cout, -1).norm(dim=1).reshape(cout, 1, 1))
+        self.weight_v = nn.Parameter(v)
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self._packed = _Packed()
+
+    def packed(self) -> torch.Tensor:
+        return self._packed.get((self.weight_g, self.weight_v),
+                                lambda: ops.pack_conv1d(ops.weight_norm(self.weight_v.detach(), self.weight_g.detach())))
+
+    def folded_weight(self) -> torch.Tensor:
+        return ops.weight_norm(self.weight_v.detach(), self.weight_g.detach())
+
+    def run(self, x, alpha_in=None, residual=None, alpha_out=None, tanh=False):
+        return ops.conv1d(x, self.packed(), self.cout, self.ks, bias=self.bias.detach(), stride=self.stride,
+                          dil=self.dilation, pad=self.padding, alpha_in=alpha_in, residual=residual,
+                          alpha_out=alpha_out, tanh=tanh)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class WNConvTranspose1d(nn.Module):
+    """weight_norm(nn.ConvTranspose1d) parameter holder; weight_v is [Cin, Cout, k], norm over dim 0."""
+
+    def __init__(self, cin, cout, kernel_size, stride, padding):
+        super().__init__()
+        if kernel_size != 2 * stride:
+            raise MvqError("WNConvTranspose1d: the path covers kernel_size == 2*stride (every DAC DecoderBlock)")
+        self.cin, self.cout, self.ks, self.stride, self.padding = cin, cout, kernel_size, stride, padding
+        v = torch.randn(cin, cout, kernel_size) / math.sqrt(cin * 2)
+        self.weight_g = nn.Parameter(v.reshape(cin, -1).norm(dim=1).reshape(cin, 1, 1))
+        self.weight_v = nn.Parameter(v)
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self._packed = _Packed()
+
+    def packed(self) -> torch.Tensor:
+        return self._packed.get((self.weight_g, self.weight_v),
+                                lambda: ops.pack_conv_transpose1d(
+                                    ops.weight_norm(self.weight_v.detach(), self.weight_g.detach()), self.stride))
+
+    def run(self, x, alpha_in=None, alpha_out=None):
+        return ops.conv_transpose1d(x, self.packed(), self.cout, self.stride, self.padding, bias=self.bias.detach(),
+                                    alpha_in=alpha_in, alpha_out=alpha_out)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class ResidualUnit(nn.Module):
+    """x + conv1(snake(conv7_dilated(snake(x))))  -- two launches: the first applies Snake on load and the
+    second Snake on store, the second adds the skip (and optionally the NEXT layer's Snake) in its epilogue."""
+
+    def __init__(self, dim: int, dilation: int):
+        super().__init__()
+        pad = ((7 - 1) * dilation) // 2
+        self.block = nn.Sequential(Snake1d(dim), WNConv1d(dim, dim, 7, dilation=dilation, padding=pad),
+                                   Snake1d(dim), WNConv1d(dim, dim, 1))
+
+    def run(self, x, alpha_next=None):
+        h = self.block[1].run(x, alpha_in=self.block[0].flat(), alpha_out=self.block[2].flat())
+        return self.block[3].run(h, residual=x, alpha_out=alpha_next)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class EncoderBlock(nn.Module):
+    def __init__(self, dim: int, stride: int):
+        super().__init__()
+        self.block = nn.Sequential(ResidualUnit(dim // 2, 1), ResidualUnit(dim // 2, 3), ResidualUnit(dim // 2, 9),
+                                   Snake1d(dim // 2),
+                                   WNConv1d(dim // 2, dim, 2 * stride, stride=stride, padding=math.ceil(stride / 2)))
+
+    def run(self, x, alpha_next=None):
+        x = self.block[0].run(x)
+        x = self.block[1].run(x)
+        x = self.block[2].run(x, alpha_next=self.block[3].flat())     # Snake before the strided conv, fused
+        return self.block[4].run(x, alpha_out=alpha_next)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class Encoder(nn.Module):
+    """x[B,1,T] -> [B,d_latent,T/prod(strides)]  (36.8 GFLOP per 1-s segment at 24 kHz)."""
+
+    def __init__(self, d_model: int = 64, strides=ENC_RATES, d_latent: int = 1024):
+        super().__init__()
+        layers: List[nn.Module] = [WNConv1d(1, d_model, 7, padding=3)]
+        for s in strides:
+            d_model *= 2
+            layers.append(EncoderBlock(d_model, s))
+        layers += [Snake1d(d_model), WNConv1d(d_model, d_latent, 3, padding=1)]
+        self.block = nn.Sequential(*layers)
+        self.enc_dim = d_model
+
+    @torch.no_grad()
+    def forward(self, x):
+        n = len(self.block)
+        h = self.block[0].run(x)
+        for i in range(1, n - 2):
+            last = i == n - 3
+            h = self.block[i].run(h, alpha_next=self.block[n - 2].flat() if last else None)
+        return self.block[n - 1].run(h)
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, input_dim: int, output_dim: int, stride: int):
+        super().__init__()
+        self.block = nn.Sequential(Snake1d(input_dim),
+                                   WNConvTranspose1d(input_dim, output_dim, 2 * stride, stride, math.ceil(stride / 2)),
+                                   ResidualUnit(output_dim, 1), ResidualUnit(output_dim, 3), ResidualUnit(output_dim, 9))
+
+    def run(self, x, alpha_next=None, pre_snaked=False):
+        """`pre_snaked`: x already carries this block's leading Snake (fused into its producer's epilogue)."""
+        h = self.block[1].run(x, alpha_in=None if pre_snaked else self.block[0].flat())
+        h = self.block[2].run(h)
+        h = self.block[3].run(h)
+        return self.block[4].run(h, alpha_next=alpha_next)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class Decoder(nn.Module):
+    """z[B,C,Tl] -> [B,1,~Tl*prod(rates)]  (83.4 GFLOP per segment)."""
+
+    def __init__(self, input_channel: int = 1024, channels: int = 1536, rates=DEC_RATES, d_out: int = 1):
+        super().__init__()
+        layers: List[nn.Module] = [WNConv1d(input_channel, channels, 7, padding=3)]
+        out = channels
+        for i, s in enumerate(rates):
+            inp, out = channels // 2 ** i, channels // 2 ** (i + 1)
+            layers.append(DecoderBlock(inp, out, s))
+        layers += [Snake1d(out), WNConv1d(out, d_out, 7, padding=3), nn.Tanh()]
+        self.model = nn.Sequential(*layers)
+
+    @torch.no_grad()
+    def forward(self, z):
+        m = self.model
+        nblk = len(m) - 4
+        h = m[0].run(z, alpha_out=m[1].block[0].flat())
+        for i in range(1, nblk + 1):
+            nxt = m[i + 1].block[0].flat() if i < nblk else m[nblk + 1].flat()
+            h = m[i].run(h, alpha_next=nxt, pre_snaked=True)
+        return m[nblk + 2].run(h, tanh=True)
+
+
+class VectorQuantize(nn.Module):
+    def __init__(self, input_dim: int, codebook_size: int, codebook_dim: int):
+        super().__init__()
+        self.in_proj = WNConv1d(input_dim, codebook_dim, 1)
+        self.out_proj = WNConv1d(codebook_dim, input_dim, 1)
+        self.codebook = nn.Embedding(codebook_size, codebook_dim)
+
+
+class ResidualVectorQuantize(nn.Module):
+    """DAC residual VQ (eval semantics): all stages in one fused launch (mvq_dac_rvq_f32)."""
+
+    def __init__(self, input_dim: int = 1024, n_codebooks: int = 32, codebook_size: int = 1024,
+                 codebook_dim: int = 8, quantizer_dropout: float = 0.0):
+        super().__init__()
+        self.n_codebooks, self.codebook_size, self.codebook_dim = n_codebooks, codebook_size, codebook_dim
+        self.n_q, self.bins = n_codebooks, codebook_size       # probed by get_n_books_and_bins (…5_eval.py:233-246)
+        self.quantizers = nn.ModuleList([VectorQuantize(input_dim, codebook_size, codebook_dim)
+                                         for _ in range(n_codebooks)])
+        self._stacked = _Packed()
+
+    def _weights(self):
+        qs = self.quantizers
+
+        def make():
+            in_w = torch.stack([q.in_proj.folded_weight().reshape(self.codebook_dim, -1) for q in qs]).contiguous()
+            out_w = torch.stack([q.out_proj.folded_weight().reshape(-1, self.codebook_dim) for q in qs]).contiguous()
+            in_b = torch.stack([q.in_proj.bias.detach() for q in qs]).contiguous()
+            out_b = torch.stack([q.out_proj.bias.detach() for q in qs]).contiguous()
+            cb = torch.stack([q.codebook.weight.detach() for q in qs]).contiguous()
+            return in_w, in_b, cb, out_w, out_b
+
+        params = [p for q in qs for p in (q.in_proj.weight_g, q.in_proj.weight_v, q.in_proj.bias,
+                                          q.out_proj.weight_g, q.out_proj.weight_v, q.out_proj.bias,
+                                          q.codebook.weight)]
+        return self._stacked.get(params, make)
+
+    @torch.no_grad()
+    def forward(self, z, n_quantizers: Optional[int] = None):
+        nq = self.n_codebooks if n_quantizers is None else max(1, min(int(n_quantizers), self.n_codebooks))
+        in_w, in_b, cb, out_w, out_b = self._weights()
+        zq, codes, latents = ops.dac_rvq(z, in_w, in_b, cb, out_w, out_b, nq)
+        zero = torch.zeros((), device=zq.device)
+        return zq, codes, latents, zero, zero.clone()
+
+
+class DAC(nn.Module):
+    """encoder / quantizer / decoder with the 24 kHz hyper-parameters; ``encode`` / ``decode`` as upstream."""
+
+    def __init__(self, encoder_dim=64, encoder_rates=ENC_RATES, latent_dim=None, decoder_dim=1536,
+                 decoder_rates=DEC_RATES, n_codebooks=32, codebook_size=1024, codebook_dim=8, sample_rate=24000):
+        super().__init__()
+        if latent_dim is None:
+            latent_dim = encoder_dim * (2 ** len(encoder_rates))
+        self.sample_rate = sample_rate
+        self.hop_length = int(math.prod(encoder_rates))
+        self.encoder = Encoder(encoder_dim, encoder_rates, latent_dim)
+        self.quantizer = ResidualVectorQuantize(latent_dim, n_codebooks, codebook_size, codebook_dim)
+        self.decoder = Decoder(latent_dim, decoder_dim, decoder_rates)
+
+    @classmethod
+    def load(cls, path, **kw):
+        """Load a LOCAL state dict (there is no downloader: the reference's dac.utils.download is a network fetch)."""
+        obj = torch.load(str(path), map_location="cpu")
+        sd = obj.get("state_dict", obj) if isinstance(obj, dict) else obj
+        model = cls(**kw)
+        model.load_state_dict(sd, strict=True)
+        return model
+
+    @torch.no_grad()
+    def encode(self, audio_data, n_quantizers: Optional[int] = None):
+        z = self.encoder(audio_data)
+        return self.quantizer(z, n_quantizers)
+
+    @torch.no_grad()
+    def decode(self, z):
+        return self.decoder(z)
+
+    @torch.no_grad()
+    def forward(self, audio_data, sample_rate=None, n_quantizers=None):
+        length = audio_data.shape[-1]
+        pad = (-length) % self.hop_length
+        x = torch.nn.functional.pad(audio_data, (0, pad))
+        z, codes, latents, cl, cbl = self.encode(x, n_quantizers)
+        y = self.decode(z)
+        return {"audio": y[..., :length], "z": z, "codes": codes, "latents": latents,
+                "vq/commitment_loss": cl, "vq/codebook_loss": cbl}

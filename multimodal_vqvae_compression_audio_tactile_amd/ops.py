@@ -142,25 +142,37 @@ def dac_rvq(z, in_w, in_b, codebook, out_w, out_b, n_q):
     return zq, codes.long(), lat
 
 
-def layernorm_c(x, gamma, beta, pe=None, eps=1e-5, do_tanh=False, post_scale=1.0):
+def layernorm_c(x, gamma, beta, pe=None, eps=1e-5, do_tanh=False, post_scale=1.0, folded_batch=None):
+    """LayerNorm over channels of x[B,C,T]; with ``folded_batch=B`` x is the token-folded [1,C,B*T] layout."""
     x = _dev(x, "x")
     B, C, T = x.shape
+    sb = sc = 0
+    if folded_batch is not None:
+        if B != 1 or T % folded_batch:
+            raise MvqError("layernorm_c: folded tensor must be [1, C, B*T]")
+        B, T = folded_batch, T // folded_batch
+        sb, sc = T, B * T
     y = torch.empty_like(x)
     if pe is not None and (pe.shape[0] < T or pe.shape[1] != C):
         raise MvqError(f"layernorm_c: pe table {tuple(pe.shape)} too small for T={T}, C={C}")
     check(_lib.lib().mvq_layernorm_c_f32(x.data_ptr(), _p(pe), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                         B, C, T, float(eps), int(do_tanh), float(post_scale), _stream()),
+                                         B, C, T, sb, sc, float(eps), int(do_tanh), float(post_scale), _stream()),
           "mvq_layernorm_c_f32")
     return y
 
 
-def attention(q, k, v, heads):
+def attention(q, k, v, heads, folded_batch=None):
     q = _dev(q, "q"); k = _dev(k, "k"); v = _dev(v, "v")
     B, C, Tq = q.shape
     Tk = k.shape[2]
+    strides = (0, 0, 0, 0)
+    if folded_batch is not None:
+        B = folded_batch
+        Tq, Tk = Tq // B, Tk // B
+        strides = (Tq, B * Tq, Tk, B * Tk)
     ctx = torch.empty_like(q)
     check(_lib.lib().mvq_attention_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), ctx.data_ptr(), B, heads, C // heads,
-                                       Tq, Tk, _stream()), "mvq_attention_f32")
+                                       Tq, Tk, *strides, _stream()), "mvq_attention_f32")
     return ctx
 
 
@@ -171,30 +183,40 @@ def gelu(x):
     return y
 
 
-def sub_time_slice(a, s, e, b):
-    """a[..., s:e] - b for a[B,C,T], b[B,C,e-s] without materialising the slice."""
-    a = _dev(a, "a"); b = _dev(b, "b")
-    B, C, T = a.shape
-    n = e - s
-    y = torch.empty(B, C, n, device=a.device, dtype=torch.float32)
-    check(_lib.lib().mvq_sub_rows_f32(a.data_ptr() + 4 * s, T, b.data_ptr(), n, y.data_ptr(), n, B * C, n, _stream()),
-          "mvq_sub_rows_f32")
-    return y
-
-
-def copy_time_slice(a, s, e):
+def fold_time_slice(a, s, e):
+    """a[B,C,T][..., s:e] -> token-folded [1, C, B*(e-s)] (column b*(e-s)+i = token i of batch element b)."""
     a = _dev(a, "a")
     B, C, T = a.shape
     n = e - s
-    y = torch.empty(B, C, n, device=a.device, dtype=torch.float32)
-    check(_lib.lib().mvq_copy_rows_f32(a.data_ptr() + 4 * s, T, y.data_ptr(), n, B * C, n, _stream()), "mvq_copy_rows_f32")
+    y = torch.empty(1, C, B * n, device=a.device, dtype=torch.float32)
+    check(_lib.lib().mvq_copy3d_f32(a.data_ptr() + 4 * s, C * T, T, y.data_ptr(), n, B * n, B, C, n, _stream()),
+          "mvq_copy3d_f32")
     return y
 
 
-def write_time_slice_(dst, s, src):
-    """dst[..., s:s+n] = src for dst[B,C,T], src[B,C,n]."""
+def unfold_into_(dst, s, src, batch):
+    """dst[B,C,T][..., s:s+n] = unfold(src[1, C, B*n])."""
     B, C, T = dst.shape
-    n = src.shape[2]
-    check(_lib.lib().mvq_copy_rows_f32(src.data_ptr(), n, dst.data_ptr() + 4 * s, T, B * C, n, _stream()),
-          "mvq_copy_rows_f32")
+    n = src.shape[2] // batch
+    check(_lib.lib().mvq_copy3d_f32(src.data_ptr(), n, B * n, dst.data_ptr() + 4 * s, C * T, T, B, C, n, _stream()),
+          "mvq_copy3d_f32")
     return dst
+
+
+def fold_column_into_(dst_folded, col, src, t, batch):
+    """dst_folded[1,C,B*n][:, :, b*n + col] = src[B,C,T][b, :, t]."""
+    B, C, T = src.shape
+    n = dst_folded.shape[2] // batch
+    check(_lib.lib().mvq_copy3d_f32(src.data_ptr() + 4 * t, C * T, T, dst_folded.data_ptr() + 4 * col, n, B * n,
+                                    B, C, 1, _stream()), "mvq_copy3d_f32")
+    return dst_folded
+
+
+def sub(a, b):
+    """a - b for equal-shaped contiguous tensors."""
+    a = _dev(a, "a"); b = _dev(b, "b")
+    y = torch.empty_like(a)
+    n = a.numel()
+    check(_lib.lib().mvq_sub3d_f32(a.data_ptr(), 0, 0, b.data_ptr(), 0, 0, y.data_ptr(), 0, 0, 1, 1, n, _stream()),
+          "mvq_sub3d_f32")
+    return y

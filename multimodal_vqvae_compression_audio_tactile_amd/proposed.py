@@ -1,0 +1,253 @@
+"""The reference's own modules on the hot path, same names / constructor arguments / state-dict keys, running on
+libmvq_hip.so:  PosEnc1D, TokenNorm, CrossPredictor, ResidualVQEMA, AllPredAR (forward), ProposedEval.
+
+Reference: Training/compare_dacvsproposal_5.py:214-326 (train-time classes) and
+Evaluation/dac_vcpwq_proposed6_latency.py:339-487 (eval-time classes with ``n_books_use`` / ``encode_latents``).
+
+MI355X-first differences that do not change results:
+  * inside the AR loop every chunk tensor is kept TOKEN-FOLDED as [1, C, B*Tc] (column b*Tc+i), so the six
+    predictor GEMMs, proj_down/up and the RVQ search see N = B*Tc contiguous columns instead of B tiny
+    [C,16] problems; LayerNorm / attention take (batch, channel) strides for that layout;
+  * PosEnc1D add is fused into the LayerNorm kernel, tanh and the clamp(scale) multiply into TokenNorm's,
+    residual adds into GEMM epilogues;
+  * the shift-by-one input ``zt_prev`` is built exactly as the reference does (only column 0 of a chunk with
+    s > 0 is non-zero -- SURVEY.md section 3.1 "Observed data dependency").
+Dropout is the identity here (eval semantics); train-mode dropout / backward are not part of this round.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import MvqError
+from .dac import _Packed
+
+CODE_DIM = 96        # Training/compare_dacvsproposal_5.py:68
+AR_CHUNK_TOK = 16    # ...:65
+EMA_DECAY = 0.99     # ...:69
+
+
+class PosEnc1D(nn.Module):
+    def __init__(self, c, max_len=8192):
+        super().__init__()
+        pe = torch.zeros(max_len, c)
+        pos = torch.arange(0, max_len).unsqueeze(1)
+        div = torch.exp(torch.arange(0, c, 2) * (-math.log(10000.0) / c))
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        self.register_buffer("pe", pe)
+
+
+class TokenNorm(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.ln = nn.LayerNorm(c)
+
+    @torch.no_grad()
+    def forward(self, z):
+        return ops.layernorm_c(z, self.ln.weight.detach(), self.ln.bias.detach(), eps=self.ln.eps)
+
+
+class _PackedLinear:
+    """K-major packed image of an nn.Linear / 1x1 nn.Conv1d weight, rebuilt when the parameter changes."""
+
+    def __init__(self, mod):
+        self.mod = mod
+        self.cache = _Packed()
+
+    def wp(self):
+        w = self.mod.weight
+        return self.cache.get((w,), lambda: ops.pack_conv1d(w.detach().reshape(w.shape[0], w.shape[1], 1)))
+
+    def __call__(self, x, residual=None):
+        w = self.mod.weight
+        b = self.mod.bias.detach() if getattr(self.mod, "bias", None) is not None else None
+        return ops.conv1d(x, self.wp(), w.shape[0], 1, bias=b, residual=residual)
+
+
+class CrossPredictor(nn.Module):
+    def __init__(self, c, heads=8, mlp_mul=2, dropout=0.1):
+        super().__init__()
+        assert c % heads == 0
+        self.pos = PosEnc1D(c)
+        self.h, self.dh = heads, c // heads
+        self.ln_q, self.ln_kv = nn.LayerNorm(c), nn.LayerNorm(c)
+        self.q_proj, self.k_proj, self.v_proj = nn.Linear(c, c, False), nn.Linear(c, c, False), nn.Linear(c, c, False)
+        self.out = nn.Linear(c, c, False)
+        self.drop = nn.Dropout(dropout)
+        self.ffn = nn.Sequential(nn.LayerNorm(c), nn.Linear(c, mlp_mul * c), nn.GELU(), nn.Linear(mlp_mul * c, c))
+        self._lin = {n: _PackedLinear(m) for n, m in (("q", self.q_proj), ("k", self.k_proj), ("v", self.v_proj),
+                                                      ("o", self.out), ("f1", self.ffn[1]), ("f3", self.ffn[3]))}
+
+    @torch.no_grad()
+    def run(self, zt_prev, za, folded_batch=None):
+        """zt_prev[B,C,Tq], za[B,C,Tk] (or both token-folded [1,C,B*T] with folded_batch=B) -> same layout."""
+        fb = folded_batch
+        pe = self.pos.pe
+        q = ops.layernorm_c(zt_prev, self.ln_q.weight.detach(), self.ln_q.bias.detach(), pe=pe, eps=self.ln_q.eps,
+                            folded_batch=fb)
+        kv = ops.layernorm_c(za, self.ln_kv.weight.detach(), self.ln_kv.bias.detach(), pe=pe, eps=self.ln_kv.eps,
+                             folded_batch=fb)
+        L = self._lin
+        Q, K, V = L["q"](q), L["k"](kv), L["v"](kv)
+        ctx = ops.attention(Q, K, V, self.h, folded_batch=fb)
+        y1 = L["o"](ctx, residual=q)                                        # out(ctx) + q
+        hdn = ops.layernorm_c(y1, self.ffn[0].weight.detach(), self.ffn[0].bias.detach(), eps=self.ffn[0].eps,
+                              folded_batch=fb)
+        hdn = ops.gelu(L["f1"](hdn))
+        return L["f3"](hdn, residual=y1)                                    # ffn(y) + y
+
+    def forward(self, zt_prev, za):
+        if self.training and self.drop.p > 0:
+            raise MvqError("CrossPredictor: train-mode dropout is outside this round's scope; call .eval()")
+        return self.run(zt_prev, za)
+
+
+class ResidualVQEMA(nn.Module):
+    """Residual VQ with EMA codebooks.  ``forward(z[B,D,T], n_books_use=None)``; ``ema_step(z_tokens)``."""
+
+    def __init__(self, dim: int, n_books: int, n_embed: int, decay: float = EMA_DECAY):
+        super().__init__()
+        self.books = nn.ParameterList([nn.Parameter(torch.randn(n_embed, dim) / math.sqrt(dim))
+                                       for _ in range(n_books)])
+        self.decay = float(decay)
+        self.n_books, self.n_embed = int(n_books), int(n_embed)
+        self._stack = _Packed()
+
+    def stacked(self) -> torch.Tensor:
+        bs = list(self.books)
+        return self._stack.get(bs, lambda: torch.stack([b.detach().float() for b in bs]).contiguous())
+
+    @torch.no_grad()
+    def forward(self, z, n_books_use: Optional[int] = None, return_indices: bool = False):
+        if len(self.books) == 0:
+            return torch.zeros_like(z)
+        return ops.rvq_ema_forward(z, self.stacked(), n_books_use, return_indices=return_indices)
+
+    @torch.no_grad()
+    def ema_step(self, z_tokens):
+        books = self.stacked().clone()
+        ops.rvq_ema_step_(z_tokens, books, self.decay)
+        for i, p in enumerate(self.books):
+            p.data.copy_(books[i])
+
+
+class _ProposedBase(nn.Module):
+    def __init__(self, A_ENC, A_QUANT, T_ENC, T_DEC, c_lat, rvq_books, rvq_embed, decay=EMA_DECAY):
+        super().__init__()
+        self.A_ENC, self.A_QUANT, self.T_ENC, self.T_DEC = A_ENC, A_QUANT, T_ENC, T_DEC
+        for m in [self.A_ENC, self.A_QUANT, self.T_ENC, self.T_DEC]:
+            if m is not None:
+                for p in m.parameters():
+                    p.requires_grad_(False)
+        self.predict = CrossPredictor(c=c_lat, heads=8, mlp_mul=2, dropout=0.1)
+        self.tokennorm = TokenNorm(c_lat)
+        self.scale = nn.Parameter(torch.tensor(0.08))
+        self.proj_down = nn.Conv1d(c_lat, CODE_DIM, 1)
+        self.proj_up = nn.Conv1d(CODE_DIM, c_lat, 1)
+        self.vq = ResidualVQEMA(dim=CODE_DIM, n_books=rvq_books, n_embed=rvq_embed, decay=decay)
+        self._pd, self._pu = _PackedLinear(self.proj_down), _PackedLinear(self.proj_up)
+        self._scale_host = None
+
+    def _scale_value(self) -> float:
+        """clamp(scale, 5e-3, 0.5) as a host float (one device read, cached per parameter version)."""
+        key = (self.scale._version, self.scale.data_ptr())
+        if self._scale_host is None or self._scale_host[0] != key:
+            v = float(self.scale.detach().float().clamp(5e-3, 0.5).item())
+            self._scale_host = (key, v)
+        return self._scale_host[1]
+
+    @torch.no_grad()
+    def _ar_latents(self, qa, zt, books_use=None, want_tokens=False, tactile_only=False):
+        """The chunked AR loop (Training/...5.py:302-320 == Evaluation/...6_latency.py:461-477)."""
+        B, C, Tlat = zt.shape
+        z_run = torch.zeros_like(zt)
+        r_tokens = torch.empty(B, CODE_DIM, Tlat, device=zt.device, dtype=torch.float32) if want_tokens else None
+        scale = self._scale_value()
+        ln = self.tokennorm.ln
+        for s in range(0, Tlat, AR_CHUNK_TOK):
+            e = min(Tlat, s + AR_CHUNK_TOK)
+            n = e - s
+            zt_c = ops.fold_time_slice(zt, s, e)                             # [1,C,B*n]
+            if tactile_only:
+                z_pred, r = None, zt_c
+            else:
+                zt_prev = torch.zeros(1, C, B * n, device=zt.device, dtype=torch.float32)
+                if s > 0:                                                     # column 0 <- z_run[..., s-1]
+                    ops.fold_column_into_(zt_prev, 0, z_run, s - 1, B)
+                ka = min(qa.shape[-1], e) - min(qa.shape[-1], s)              # audio may be shorter (whole-file mode)
+                qa_c = ops.fold_time_slice(qa, s, s + ka) if ka > 0 else torch.zeros(1, C, 0, device=zt.device)
+                z_pred = self.predict.run(zt_prev, qa_c, folded_batch=B)
+                r = ops.sub(zt_c, z_pred)
+            rN = ops.layernorm_c(r, ln.weight.detach(), ln.bias.detach(), eps=ln.eps, do_tanh=True, post_scale=scale,
+                                 folded_batch=B)
+            rD = self._pd(rN)                                                 # [1,96,B*n]
+            qD = self.vq(rD, n_books_use=books_use)
+            z_hat = self._pu(qD, residual=z_pred)
+            ops.unfold_into_(z_run, s, z_hat, B)
+            if want_tokens:
+                ops.unfold_into_(r_tokens, s, rD, B)
+        return z_run, r_tokens
+
+
+class ProposedEval(_ProposedBase):
+    """Evaluation/dac_vcpwq_proposed6_latency.py:437-487."""
+
+    @torch.no_grad()
+    def encode_latents(self, a_1T, t_1T, books_use=None):
+        za = self.A_ENC(a_1T)
+        qa, *_ = self.A_QUANT(za)
+        zt = self.T_ENC(t_1T)
+        z_run, _ = self._ar_latents(qa, zt, books_use)
+        return z_run
+
+    @torch.no_grad()
+    def forward_eval(self, a_1T, t_1T, books_use=None):
+        return self.T_DEC(self.encode_latents(a_1T, t_1T, books_use=books_use))
+
+    @torch.no_grad()
+    def encode_latents_tactile_only(self, t_1T, books_use=None):
+        """BASELINE.json configs[1]: the tactile-side chain with z_pred == 0:
+        T_ENC -> tanh(TokenNorm)*scale -> proj_down -> RVQ -> proj_up."""
+        zt = self.T_ENC(t_1T)
+        z_run, _ = self._ar_latents(None, zt, books_use, tactile_only=True)
+        return z_run
+
+    @torch.no_grad()
+    def forward_eval_tactile_only(self, t_1T, books_use=None):
+        return self.T_DEC(self.encode_latents_tactile_only(t_1T, books_use))
+
+
+class AllPredAR(_ProposedBase):
+    """Training/compare_dacvsproposal_5.py:279-326 -- forward pass only (eval semantics)."""
+
+    @torch.no_grad()
+    def forward_step(self, a_1T, tc_1T):
+        Tw = tc_1T.shape[-1]
+        za = self.A_ENC(a_1T)
+        qa, *_ = self.A_QUANT(za)
+        zt = self.T_ENC(tc_1T)
+        z_run, r_tokens = self._ar_latents(qa, zt, None, want_tokens=True)
+        y_hat = self.T_DEC(z_run)
+        T = min(y_hat.shape[-1], tc_1T.shape[-1], Tw)
+        fz = lambda x: torch.nan_to_num(x, nan=0.0, posinf=0.0, neginf=0.0)   # finite_or_zero (...5.py:99-100)
+        return {"y_hat": fz(y_hat[..., :T]), "tgt": fz(tc_1T[..., :T]), "r_tokens": r_tokens}
+
+
+def psnr_batch(ref_1T, est_1T, eps=1e-12):
+    """PSNR(dB), peak = 1.0 (Evaluation/compare_dacvsproposal_5_eval.py:180-185)."""
+    ref = ref_1T.to(torch.float32); est = est_1T.to(torch.float32)
+    mse = (ref - est).pow(2).mean(dim=(1, 2)).clamp_min(eps)
+    return [float(v) for v in (10.0 * torch.log10(1.0 / mse)).cpu()]
+
+
+def psnr_global_peak_db(ref, est, peak, eps=1e-12):
+    """Evaluation/dac_vcpwq_proposed6_latency.py:204-214."""
+    ref = ref.reshape(-1).to(torch.float32); est = est.reshape(-1).to(torch.float32)
+    mse = torch.mean((ref - est) ** 2) + eps
+    peak = max(float(peak), eps)
+    return float(10.0 * torch.log10((peak * peak) / mse).cpu())

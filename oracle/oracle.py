@@ -339,13 +339,15 @@ def cross_predictor(sd, zt_prev, za, pe, heads=8, prefix="predict."):
     return _linear(h, sd[P + "ffn.3.weight"], sd[P + "ffn.3.bias"], residual=y1)   # ffn(y+q) + (y+q)
 
 
-def proposed_encode_latents(sd, a, t, books_use=None, pe=None, return_aux=False):
+def proposed_encode_latents(sd, a, t, books_use=None, pe=None, return_aux=False, tactile_only=False):
     """ProposedEval.encode_latents / AllPredAR.forward_step (forward part).
 
     sd holds the checkpoint names of the reference model: A_ENC.*, A_QUANT.*, T_ENC.*, T_DEC.*,
     predict.*, tokennorm.ln.*, scale, proj_down.*, proj_up.*, vq.books.{i}."""
-    za = dac_encoder(sd, a, prefix="A_ENC.")
-    qa = dac_quantizer(sd, za, prefix="A_QUANT.")[0]
+    za = qa = None
+    if not tactile_only:      # tactile_only: SURVEY.md section 8d config 2 (z_pred == 0, no audio branch)
+        za = dac_encoder(sd, a, prefix="A_ENC.")
+        qa = dac_quantizer(sd, za, prefix="A_QUANT.")[0]
     zt = dac_encoder(sd, t, prefix="T_ENC.")
     B, C, Tlat = zt.shape
     if pe is None:
@@ -363,8 +365,12 @@ def proposed_encode_latents(sd, a, t, books_use=None, pe=None, return_aux=False)
             zt_prev[..., 1:] = z_run[..., s:e - 1]
         else:
             zt_prev[...] = z_run[..., s - 1:e - 1]
-        z_pred = cross_predictor(sd, zt_prev, qa[..., s:e], pe)
-        r = zt[..., s:e] - z_pred
+        if tactile_only:
+            z_pred = None
+            r = zt[..., s:e]
+        else:
+            z_pred = cross_predictor(sd, zt_prev, qa[..., s:e], pe)
+            r = zt[..., s:e] - z_pred
         rN = layernorm_c(r, sd["tokennorm.ln.weight"], sd["tokennorm.ln.bias"], do_tanh=True, post_scale=scale)
         rD = conv1d(rN, np.asarray(sd["proj_down.weight"], np.float32), sd["proj_down.bias"])
         qD, idx = rvq_ema_forward(rD, books, books_use)
@@ -377,8 +383,8 @@ def proposed_encode_latents(sd, a, t, books_use=None, pe=None, return_aux=False)
     return z_run
 
 
-def proposed_forward_eval(sd, a, t, books_use=None, pe=None):
-    z_run = proposed_encode_latents(sd, a, t, books_use, pe)
+def proposed_forward_eval(sd, a, t, books_use=None, pe=None, tactile_only=False):
+    z_run = proposed_encode_latents(sd, a, t, books_use, pe, tactile_only=tactile_only)
     return dac_decoder(sd, z_run, prefix="T_DEC.")
 
 
