@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- encode + VQ + decode throughput of the MI355X path (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one pass of the hot path over one batch of synthetic paired segments that is already resident in
+HBM: ProposedEval.forward_eval (A_ENC + 32-book A_QUANT + T_ENC + 5 AR chunks with 8x512 RVQ + T_DEC) over
+``--batch`` 1-second segments per GPU (75 token-frames each).  Segments are independent, so ranks shard them with no
+data-path collective ("weak" scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     -- the dominant kernel (largest share of device time among conv1d_mfma instantiations): algorithmic
+                  FLOPs per launch / its average duration measured with HIP events on the launch stream during the
+                  timed steps, against the fp32 MFMA peak (157.3 TFLOP/s).
+  cpu_baseline -- the torch-CPU restatement of the same path (oracle/dac24_torch.py, "port") timed on this node's
+                  host cores on a bounded sample, rank 0 / N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from collections import defaultdict
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+GFLOP_PER_SEGMENT = {"joint": 158.5, "tactile": 120.3}
+TOKENS_PER_SEGMENT = 75
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="1-s segments per GPU per step")
+    ap.add_argument("--workload", choices=["joint", "tactile"], default="joint")
+    ap.add_argument("--books", type=int, default=8)
+    ap.add_argument("--embed", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline = null)")
+    return ap.parse_args()
+
+
+class KernelEvents:
+    """Per-launch HIP event pairs on the launch stream (torch's current stream IS the stream ops.* launch on)."""
+
+    def __init__(self):
+        self.records = []
+
+    def wrap(self, ops):
+        orig_conv, orig_tr = ops.conv1d, ops.conv_transpose1d
+        rec = self.records
+
+        def conv1d(x, wp, cout, ks, bias=None, stride=1, dil=1, pad=0, **kw):
+            B, cin, tin = x.shape
+            tout = ops.conv1d_out_len(tin, ks, stride, dil, pad)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig_conv(x, wp, cout, ks, bias=bias, stride=stride, dil=dil, pad=pad, **kw)
+            e1.record()
+            rec.append((ops.conv_kernel_name(cin, cout, ks, stride, dil), 2.0 * cin * cout * ks * tout * B, e0, e1))
+            return y
+
+        def conv_transpose1d(x, wp, cout, stride, pad, **kw):
+            B, cin, tin = x.shape
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig_tr(x, wp, cout, stride, pad, **kw)
+            e1.record()
+            rec.append((ops.conv_kernel_name(cin, cout, 2 * stride, stride, 1, transposed=True),
+                        2.0 * cin * cout * 2 * stride * tin * B, e0, e1))
+            return y
+
+        ops.conv1d, ops.conv_transpose1d = conv1d, conv_transpose1d
+        self._restore = lambda: (setattr(ops, "conv1d", orig_conv), setattr(ops, "conv_transpose1d", orig_tr))
+
+    def summary(self):
+        tot = defaultdict(lambda: [0.0, 0.0, 0])
+        for name, flops, e0, e1 in self.records:
+            t = tot[name]
+            t[0] += e0.elapsed_time(e1) * 1e-3
+            t[1] += flops
+            t[2] += 1
+        return {k: {"seconds": v[0], "flops": v[1], "launches": v[2]} for k, v in tot.items()}
+
+
+def cpu_baseline(workload, books, embed, sd):
+    """torch-CPU restatement on the host cores: bounded sample (B=6, the reference batch; 1 warm-up + timed reps
+    until ~15 s)."""
+    from oracle import dac24_torch as T
+    from multimodal_vqvae_compression_audio_tactile_amd import synth
+    threads = torch.get_num_threads()
+    net = T.ProposedEval(rvq_books=books, rvq_embed=embed).eval()
+    missing = net.load_state_dict(sd, strict=True)
+    B = 6
+    a, t = synth.audio_segments(B, seed=7), synth.tactile_segments(B, seed=7)
+    tact = workload == "tactile"
+    with torch.no_grad():
+        t0 = time.perf_counter(); net.forward_eval(a[:1], t[:1], tactile_only=tact); warm = time.perf_counter() - t0
+        reps, spent = 0, 0.0
+        while spent < 15.0 and reps < 10:
+            t0 = time.perf_counter(); net.forward_eval(a, t, tactile_only=tact); spent += time.perf_counter() - t0
+            reps += 1
+    seg_s = B * reps / spent
+    return {"value": seg_s * TOKENS_PER_SEGMENT, "unit": "token-frames/s", "cores": threads, "kind": "port",
+            "segments_per_s": seg_s,
+            "sample": f"{reps} x forward_eval on B={B} synthetic 1-s segments ({workload}), torch {torch.__version__} "
+                      f"CPU fp32 restatement (oracle/dac24_torch.py), {threads} threads, warm-up {warm:.1f}s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (HIP device); there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    import multimodal_vqvae_compression_audio_tactile_amd as mvq
+    from multimodal_vqvae_compression_audio_tactile_amd import ops, synth
+
+    sd = synth.proposed_model_state(7, rvq_books=args.books, rvq_embed=args.embed)
+    net = mvq.build_proposed(sd, rvq_books=args.books, rvq_embed=args.embed, device=dev)
+    B = args.batch
+    a = synth.audio_segments(B, seed=7 + rank).to(dev)
+    t = synth.tactile_segments(B, seed=7 + rank).to(dev)
+    tact = args.workload == "tactile"
+
+    def step():
+        if tact:
+            return net.forward_eval_tactile_only(t, books_use=None)
+        return net.forward_eval(a, t, books_use=None)
+
+    for _ in range(args.warmup):
+        y = step()
+    torch.cuda.synchronize()
+
+    kev = None
+    if not args.no_kernel_events:
+        kev = KernelEvents(); kev.wrap(ops)
+
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if kev: kev._restore()
+
+    if dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    out_ok = bool(torch.isfinite(y).all().item()) and y.shape[0] == B
+
+    if rank == 0:
+        segs = B * world * args.steps
+        seg_s = segs / elapsed
+        line = {
+            "metric": "encode+VQ+decode token-frames/sec (1 frame = 13.33 ms of paired 24 kHz audio+tactile)",
+            "value": seg_s * TOKENS_PER_SEGMENT, "unit": "token-frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "segments_per_s": seg_s, "output_finite": out_ok,
+            "config": {"workload": ("joint audio+tactile ProposedEval.forward_eval (compare_dacvsproposal_5 config: "
+                                    "2x DAC-24k encoder, 32x1024x8 audio RVQ, CrossPredictor AR x5 chunks, "
+                                    f"RVQ {args.books}x{args.embed}x96, DAC-24k decoder)") if not tact else
+                                   (f"tactile-only chain: T_ENC -> TokenNorm/tanh -> proj_down -> RVQ {args.books}x{args.embed}x96 "
+                                    "-> proj_up -> T_DEC"),
+                       "segments_per_gpu_per_step": B, "segment": "1 s @ 24 kHz = 75 token-frames",
+                       "sharding": f"segments sharded over {world} GPU(s), no data-path collective",
+                       "weights": "seeded variance-preserving random init of the DAC-24k architecture"},
+        }
+        gf = GFLOP_PER_SEGMENT[args.workload]
+        line["path_tflops"] = seg_s * gf * 1e-3 / world            # per GPU, algorithmic
+        if kev:
+            summ = kev.summary()
+            dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
+            name, d = dom
+            ach = d["flops"] / d["seconds"] * 1e-12
+            traffic = None
+            pmc = ROOT / "profiles" / "pmc_traffic.json"
+            if pmc.exists():
+                try:
+                    traffic = json.loads(pmc.read_text()).get(name, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                                "launches": d["launches"], "avg_launch_us": 1e6 * d["seconds"] / d["launches"],
+                                "flop_per_launch": d["flops"] / d["launches"],
+                                "share_of_conv_time": d["seconds"] / sum(v["seconds"] for v in summ.values())}
+            conv_s = sum(v["seconds"] for v in summ.values()); conv_f = sum(v["flops"] for v in summ.values())
+            line["conv_stack"] = {"tflops": conv_f / conv_s * 1e-12, "seconds_per_step": conv_s / args.steps,
+                                  "kernels": {k: {"tflops": v["flops"] / v["seconds"] * 1e-12,
+                                                  "ms_per_step": 1e3 * v["seconds"] / args.steps,
+                                                  "launches_per_step": v["launches"] // args.steps}
+                                              for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])}}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.workload, args.books, args.embed, sd)
+                line["speedup_vs_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+            except Exception as ex:       # the baseline is reported, never required for the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "token-frames/s", "cores": torch.get_num_threads(),
+                                        "kind": "port", "sample": f"failed: {ex!r}"}
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

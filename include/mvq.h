@@ -71,6 +71,11 @@ int mvq_conv1d_f32(const float* x, const float* wp, const float* bias, const flo
                    int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act,
                    void* stream);
 
+/* Name of the kernel instantiation the two conv entry points launch for a shape ("conv1d_mfma_kernel<...>" as
+ * rocprofv3 prints it, or "conv1d_direct_kernel"): lets bench.py match its HIP-event timings to the trace.
+ * For transposed convs pass the torch shape (cin, cout, ks = 2*stride, stride). */
+int mvq_conv_kernel_name(int cin, int cout, int ks, int stride, int dil, int transposed, char* buf, int len);
+
 /* y = snake_out( conv_transpose1d( snake_in(x) ) + bias ), kernel = 2*stride, torch `padding` = pad.
  * Replaces the Snake1d + WNConvTranspose1d at the head of every upstream DecoderBlock.
  *   Tout = (Tin-1)*stride - 2*pad + 2*stride. */

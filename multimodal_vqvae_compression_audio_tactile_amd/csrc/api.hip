@@ -79,6 +79,29 @@ int mvq_conv_transpose1d_pack_f32(const float* w, float* wp, int cin, int cout, 
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv_transpose1d_pack");
 }
 
+/* which kernel instantiation mvq_conv1d_f32 / mvq_conv_transpose1d_f32 launches for a shape (profiling aid) */
+int mvq_conv_kernel_name(int cin, int cout, int ks, int stride, int dil, int transposed, char* buf, int len)
+{
+    if (!buf || len <= 0) return fail(MVQ_EINVAL, "conv_kernel_name: bad buffer");
+    const int mrows = transposed ? cout * stride : cout;
+    const int bm = mvq::conv_tile_bm(mrows);
+    const char* tile = bm == 128 ? "2, 2, 2, 2" : (bm == 96 ? "3, 2, 1, 4" : "2, 2, 1, 4");
+    int K = 0, S = 1, D = 1, CK = 0;
+    if (transposed) {
+        if (cin % 32 == 0 && mrows >= 64) { K = 2; CK = 32; }
+    } else if (cout >= 32 && cin >= 32) {
+        if (ks == 7 && stride == 1 && cin % 8 == 0 && (dil == 1 || dil == 3 || dil == 9)) { K = 7; D = dil; CK = 8; }
+        else if (ks == 1 && stride == 1 && dil == 1 && cin % 32 == 0) { K = 1; CK = 32; }
+        else if (ks == 3 && stride == 1 && dil == 1 && cin % 16 == 0 && bm == 128) { K = 3; CK = 16; }
+        else if (ks == 2 * stride && dil == 1 && cin % 16 == 0 && bm == 128 && (stride == 2 || stride == 4 || stride == 5 || stride == 8)) {
+            K = ks; S = stride; CK = stride == 2 ? 16 : (stride == 4 ? 8 : 4);
+        }
+    }
+    if (K == 0) snprintf(buf, len, "%s", transposed ? "convtr_direct_kernel" : "conv1d_direct_kernel");
+    else snprintf(buf, len, "conv1d_mfma_kernel<%d, %d, %d, %d, %s, %s>", K, S, D, CK, tile, transposed ? "true" : "false");
+    return MVQ_OK;
+}
+
 int mvq_conv1d_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
                    const float* residual, const float* alpha_out, float* y,
                    int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act, void* stream)

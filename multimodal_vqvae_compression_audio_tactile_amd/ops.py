@@ -36,6 +36,14 @@ def conv1d_out_len(tin, ks, stride=1, dil=1, pad=0):
     return 0 if span < 0 else span // stride + 1
 
 
+def conv_kernel_name(cin, cout, ks, stride=1, dil=1, transposed=False) -> str:
+    """Kernel instantiation the library launches for this conv shape (as rocprofv3 names it)."""
+    import ctypes
+    buf = ctypes.create_string_buffer(160)
+    check(_lib.lib().mvq_conv_kernel_name(cin, cout, ks, stride, dil, int(transposed), buf, 160), "mvq_conv_kernel_name")
+    return buf.value.decode()
+
+
 def weight_norm(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     """w = v * (g / ||v||) over dim 0 rows (old-style torch weight_norm fold)."""
     v = _dev(v, "v"); g = _dev(g, "g")
