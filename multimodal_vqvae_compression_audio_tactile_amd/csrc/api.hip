@@ -85,7 +85,7 @@ int mvq_conv_kernel_name(int cin, int cout, int ks, int stride, int dil, int tra
     if (!buf || len <= 0) return fail(MVQ_EINVAL, "conv_kernel_name: bad buffer");
     const int mrows = transposed ? cout * stride : cout;
     const int bm = mvq::conv_tile_bm(mrows);
-    const char* tile = bm == 128 ? "2, 2, 2, 2" : (bm == 96 ? "3, 2, 1, 4" : "2, 2, 1, 4");
+    const char* tile = bm == 128 ? "2, 2, 2, 2" : (bm == 96 ? "3, 1, 1, 4" : "2, 2, 1, 4");
     int K = 0, S = 1, D = 1, CK = 0;
     if (transposed) {
         if (cin % 32 == 0 && mrows >= 64) { K = 2; CK = 32; }

@@ -9,13 +9,14 @@
 // arithmetic contract of include/mvq.h bit for bit.
 //
 // Block = 256 threads = 4 waves; wave tile = (32*MT) x (32*NT); block tile BM x BN.  K is walked in chunks
-// of CK input channels (CK*KS a multiple of 2); weights and the input tile (with its (KS-1)*DIL halo)
-// are double-buffered in LDS, register-staged: global loads for chunk c+1 are issued before the MFMAs of
-// chunk c and written to the other LDS buffer after them (one barrier per chunk).
-// Snake1d in front of the conv is applied while staging; bias / residual / Snake1d behind the conv /
-// tanh are applied to the accumulators.  SHUFFLE=true is the polyphase form of ConvTranspose1d
-// (kernel 2*S, stride S): a 2-tap conv over M = Cout*S rows whose row (co*S + r) is written to
-// y[co, q*S + r - P].
+// of CK input channels (CK*KS even).  Pipeline per chunk c (one barrier per chunk, two LDS buffers):
+//     issue the global loads of chunk c+1 into registers (raw, branch-free, 16-byte when rows are aligned)
+//     MFMA over chunk c out of LDS, operands for k-step s+1 fetched before the MFMAs of step s
+//     Snake1d on the loaded registers (per-channel alpha / 1/alpha from an LDS table) + LDS store of chunk c+1
+// so global latency hides behind the MFMAs and the Snake VALU work of one wave overlaps the other
+// co-resident wave's matrix work.  bias / residual / Snake1d behind the conv / tanh run on the accumulators.
+// SHUFFLE=true is the polyphase form of ConvTranspose1d (kernel 2*S, stride S): a 2-tap conv over
+// M = Cout*S rows whose row (co*S + r) is written to y[co, q*S + r - P].
 #pragma once
 #include <hip/hip_runtime.h>
 #include "det_math.hpp"
@@ -23,6 +24,7 @@
 namespace mvq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
     const float* x;         // [B, Cin, Tin]
@@ -40,6 +42,7 @@ struct ConvArgs {
     int n_tiles;            // ceil(Ncols / BN)
     int act;
     int up_s, up_p;         // SHUFFLE: stride S and torch padding P
+    int vec4;               // input rows are 16-byte aligned (Tin % 4 == 0 and x 16-byte aligned)
 };
 
 template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE>
@@ -48,25 +51,129 @@ struct ConvCfg {
     static constexpr int BN = 32 * NT * WAVES_N;
     static constexpr int KC = CK * KS;                                  // K elements per chunk
     static constexpr int XT = (BN - 1) * STRIDE + (KS - 1) * DIL + 1;    // input samples per row
-    static constexpr int XTP = XT + ((XT % 2) ? 0 : 1);                  // odd pitch
+    static constexpr int XV = (XT + 3 + 3) / 4;                          // float4 per row (aligned start, shift <= 3)
+    static constexpr int XTP = XV * 4 + 4;                               // row pitch (floats), multiple of 4
     static constexpr int W_FLOATS = KC * BM;
     static constexpr int X_FLOATS = CK * XTP;
-    static constexpr int LDS_BYTES = 2 * (W_FLOATS + X_FLOATS) * 4;
+    static constexpr int LDS_FLOATS = 2 * (W_FLOATS + X_FLOATS);
     static constexpr int W_VEC = W_FLOATS / 4;                           // float4 per chunk
     static constexpr int W_PER_THREAD = (W_VEC + 255) / 256;
-    static constexpr int X_PER_THREAD = (CK * XT + 255) / 256;
+    static constexpr int XV_TOTAL = CK * XV;
+    static constexpr int XV_PER_THREAD = (XV_TOTAL + 255) / 256;         // float4 path
+    static constexpr int XS_TOTAL = CK * XT;
+    static constexpr int XS_PER_THREAD = (XS_TOTAL + 255) / 256;         // scalar path
+    static constexpr int XREGS = (4 * XV_PER_THREAD > XS_PER_THREAD) ? 4 * XV_PER_THREAD : XS_PER_THREAD;
     static_assert(WAVES_M * WAVES_N == 4, "block is 4 waves");
     static_assert(KC % 2 == 0, "chunk K must be even (32x32x2 MFMA)");
     static_assert(BM % 4 == 0, "float4 weight staging");
 };
 
-template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a)
+// Per-thread view of one block's staging / MFMA work.  Plain force-inlined member functions over register
+// arrays (lambdas capturing the arrays by reference kept them in scratch memory).
+template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE, bool VEC>
+struct ConvTile {
+    using C = ConvCfg<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE>;
+    const float* wp; const float* xb; const float* Al;
+    float* Ws; float* Xs;
+    int tid, Tin, Cin, Mpad, m0, t_in0, g_al;
+    bool snake_in;
+
+    // stage 1: raw global loads of one chunk into registers (no dependent math here)
+    __device__ __forceinline__ void load_chunk(int chunk, f32x4 (&wreg)[C::W_PER_THREAD], f32x4 (&xv)[C::XV_PER_THREAD], float (&xs)[C::XS_PER_THREAD]) const
+    {
+        const int ci0 = chunk * CK;
+        const float* wsrc = wp + (size_t)ci0 * KS * Mpad + m0;
+#pragma unroll
+        for (int u = 0; u < C::W_PER_THREAD; ++u) {
+            int v = tid + u * 256;
+            if (C::W_VEC % 256 != 0) v = v < C::W_VEC ? v : C::W_VEC - 1;
+            const int row = v / (C::BM / 4);
+            const int c4 = v - row * (C::BM / 4);
+            wreg[u] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)row * Mpad + c4 * 4);
+        }
+        if (VEC) {
+#pragma unroll
+            for (int u = 0; u < C::XV_PER_THREAD; ++u) {
+                int e = tid + u * 256;
+                if (C::XV_TOTAL % 256 != 0) e = e < C::XV_TOTAL ? e : C::XV_TOTAL - 1;
+                const int cl = e / C::XV;
+                const int v = e - cl * C::XV;
+                const int g = g_al + 4 * v;                       // multiple of 4: fully inside or fully outside
+                const bool ok = g >= 0 && g < Tin;
+                const int gc = ok ? g : 0;
+                xv[u] = *reinterpret_cast<const f32x4*>(xb + (size_t)(ci0 + cl) * Tin + gc);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < C::XS_PER_THREAD; ++u) {
+                int e = tid + u * 256;
+                if (C::XS_TOTAL % 256 != 0) e = e < C::XS_TOTAL ? e : C::XS_TOTAL - 1;
+                const int cl = e / C::XT;
+                const int xi = e - cl * C::XT;
+                const int g = t_in0 + xi;
+                const bool ok = g >= 0 && g < Tin;
+                const int gc = ok ? g : 0;
+                xs[u] = xb[(size_t)(ci0 + cl) * Tin + gc];      // zero-fill of the halo happens in store_chunk
+            }
+        }
+    }
+
+    // stage 3: Snake1d on the registers, then LDS stores
+    __device__ __forceinline__ void store_chunk(int chunk, int buf, const f32x4 (&wreg)[C::W_PER_THREAD],
+                                                const f32x4 (&xv)[C::XV_PER_THREAD],
+                                                const float (&xs)[C::XS_PER_THREAD]) const
+    {
+        const int ci0 = chunk * CK;
+        float* wdst = Ws + buf * C::W_FLOATS;
+        float* xdst = Xs + buf * C::X_FLOATS;
+#pragma unroll
+        for (int u = 0; u < C::W_PER_THREAD; ++u) {
+            const int v = tid + u * 256;
+            if (C::W_VEC % 256 == 0 || v < C::W_VEC) *reinterpret_cast<f32x4*>(wdst + v * 4) = wreg[u];
+        }
+        if (VEC) {
+#pragma unroll
+            for (int u = 0; u < C::XV_PER_THREAD; ++u) {
+                const int e = tid + u * 256;
+                const int ec = (C::XV_TOTAL % 256 != 0 && e >= C::XV_TOTAL) ? C::XV_TOTAL - 1 : e;
+                const int cl = ec / C::XV;
+                const int v = ec - cl * C::XV;
+                const int g = g_al + 4 * v;
+                const bool ok = g >= 0 && g < Tin;
+                f32x4 q = xv[u];
+                if (!ok) q = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (snake_in) {
+                    const float al = Al[ci0 + cl], inv = Al[Cin + ci0 + cl];
+                    q.x = det_snake(q.x, al, inv); q.y = det_snake(q.y, al, inv);
+                    q.z = det_snake(q.z, al, inv); q.w = det_snake(q.w, al, inv);
+                }
+                if (C::XV_TOTAL % 256 == 0 || e < C::XV_TOTAL)
+                    *reinterpret_cast<f32x4*>(xdst + cl * C::XTP + 4 * v) = q;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < C::XS_PER_THREAD; ++u) {
+                const int e = tid + u * 256;
+                const int ec = (C::XS_TOTAL % 256 != 0 && e >= C::XS_TOTAL) ? C::XS_TOTAL - 1 : e;
+                const int cl = ec / C::XT;
+                const int xi = ec - cl * C::XT;
+                const int g = t_in0 + xi;
+                float q = (g >= 0 && g < Tin) ? xs[u] : 0.0f;
+                if (snake_in) q = det_snake(q, Al[ci0 + cl], Al[Cin + ci0 + cl]);
+                if (C::XS_TOTAL % 256 == 0 || e < C::XS_TOTAL) xdst[cl * C::XTP + xi] = q;
+            }
+        }
+    }
+};
+
+template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE, bool VEC>
+__device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
 {
     using C = ConvCfg<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ws = smem;                          // [2][KC][BM]
     float* const Xs = smem + 2 * C::W_FLOATS;        // [2][CK][XTP]
+    float* const Al = smem + C::LDS_FLOATS;          // [2][Cin]: alpha, 1/(alpha+1e-9)   (only with alpha_in)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -80,10 +187,25 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a)
     const int tile_n = blockIdx.x - b * a.n_tiles;
     const int n0 = tile_n * C::BN;
     const int m0 = blockIdx.y * C::BM;
-    const int t_in0 = n0 * STRIDE - a.pad;           // input sample of LDS column 0
+    const int t_in0 = n0 * STRIDE - a.pad;           // input sample of tile column 0
+    const int g_al = t_in0 & ~3;                     // 16-byte aligned start (floor, also for negatives)
+    const int shift = VEC ? (t_in0 - g_al) : 0;      // LDS column of tile column 0
+    const int Cin = a.Cin;
+    const int n_chunks = Cin / CK;
+    const bool snake_in = a.alpha_in != nullptr;
 
-    const int n_chunks = (a.Cin + CK - 1) / CK;
-    const float* const xb = a.x + (size_t)b * a.Cin * a.Tin;
+    if (snake_in) {
+        for (int c = tid; c < Cin; c += 256) {
+            const float al = a.alpha_in[c];
+            Al[c] = al;
+            Al[Cin + c] = 1.0f / (al + 1e-9f);
+        }
+    }
+
+    ConvTile<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE, VEC> tile;
+    tile.wp = a.wp; tile.xb = a.x + (size_t)b * Cin * a.Tin; tile.Al = Al; tile.Ws = Ws; tile.Xs = Xs;
+    tile.tid = tid; tile.Tin = a.Tin; tile.Cin = Cin; tile.Mpad = a.Mpad; tile.m0 = m0; tile.t_in0 = t_in0;
+    tile.g_al = g_al; tile.snake_in = snake_in;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -93,127 +215,109 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    float4 wreg[C::W_PER_THREAD];
-    float xreg[C::X_PER_THREAD];
+    f32x4 wreg[C::W_PER_THREAD];
+    f32x4 xv[C::XV_PER_THREAD];
+    float xs[C::XS_PER_THREAD];
 
-    auto load_chunk = [&](int chunk) {
-        const int ci0 = chunk * CK;
-        const float* wsrc = a.wp + (size_t)ci0 * KS * a.Mpad + m0;
-#pragma unroll
-        for (int u = 0; u < C::W_PER_THREAD; ++u) {
-            const int v = tid + u * 256;
-            if (C::W_VEC % 256 == 0 || v < C::W_VEC) {
-                const int row = v / (C::BM / 4);
-                const int c4 = v - row * (C::BM / 4);
-                wreg[u] = *reinterpret_cast<const float4*>(wsrc + (size_t)row * a.Mpad + c4 * 4);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < C::X_PER_THREAD; ++u) {
-            const int e = tid + u * 256;
-            float val = 0.0f;
-            if ((CK * C::XT) % 256 == 0 || e < CK * C::XT) {
-                const int cl = e / C::XT;
-                const int xi = e - cl * C::XT;
-                const int ci = ci0 + cl;
-                const int g = t_in0 + xi;
-                if (ci < a.Cin && g >= 0 && g < a.Tin) {
-                    val = xb[(size_t)ci * a.Tin + g];
-                    if (a.alpha_in) {
-                        const float al = a.alpha_in[ci];
-                        val = det_snake(val, al, 1.0f / (al + 1e-9f));
-                    }
-                }
-            }
-            xreg[u] = val;
-        }
-    };
-
-    auto store_chunk = [&](int buf) {
-        float* wdst = Ws + buf * C::W_FLOATS;
-        float* xdst = Xs + buf * C::X_FLOATS;
-#pragma unroll
-        for (int u = 0; u < C::W_PER_THREAD; ++u) {
-            const int v = tid + u * 256;
-            if (C::W_VEC % 256 == 0 || v < C::W_VEC) *reinterpret_cast<float4*>(wdst + v * 4) = wreg[u];
-        }
-#pragma unroll
-        for (int u = 0; u < C::X_PER_THREAD; ++u) {
-            const int e = tid + u * 256;
-            if ((CK * C::XT) % 256 == 0 || e < CK * C::XT) {
-                const int cl = e / C::XT;
-                const int xi = e - cl * C::XT;
-                xdst[cl * C::XTP + xi] = xreg[u];
-            }
-        }
-    };
-
-    // per-lane LDS bases
+    // stage 2: MFMA over one chunk.
+    // K index kidx = ci_local*KS + kk; a 32x32x2 step takes kidx = 2s (lanes 0-31) and 2s+1 (lanes 32-63).
+    // LDS offset of kidx: (kidx / KS) * XTP + (kidx % KS) * DIL.  The lane-half delta off(2s+1) - off(2s) takes
+    // at most two values (same channel: DIL; channel boundary: XTP - (KS-1)*DIL), folded into two lane bases.
+    constexpr int D_SAME = DIL;
+    constexpr int D_CROSS = C::XTP - (KS - 1) * DIL;
     const int a_base = h * C::BM + wm * (MT * 32) + l31;
-    const int b_base = (wn * (NT * 32) + l31) * STRIDE;
+    const int b_base = (wn * (NT * 32) + l31) * STRIDE + shift;
+    const int b_same = b_base + h * D_SAME;
+    const int b_cross = b_base + h * D_CROSS;
 
-    auto compute_chunk = [&](int buf) {
+    // one chunk of MFMAs out of LDS buffer `buf`; operands of k-step s+1 are fetched before the MFMAs of step s
+    auto mfma_chunk = [&](int buf) __attribute__((always_inline)) {
         const float* wsrc = Ws + buf * C::W_FLOATS + a_base;
-        const float* xsrc = Xs + buf * C::X_FLOATS + b_base;
+        const float* xs_same = Xs + buf * C::X_FLOATS + b_same;
+        const float* xs_cross = Xs + buf * C::X_FLOATS + b_cross;
+        float av[2][MT], bv[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) av[0][i] = wsrc[i * 32];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[0][j] = ((1 / KS) != 0 ? xs_cross : xs_same)[j * 32 * STRIDE];
 #pragma unroll
         for (int s = 0; s < C::KC / 2; ++s) {
-            constexpr int dummy = 0; (void)dummy;
-            const int k0 = 2 * s, k1 = 2 * s + 1;
-            const int off0 = (k0 / KS) * C::XTP + (k0 % KS) * DIL;
-            const int off1 = (k1 / KS) * C::XTP + (k1 % KS) * DIL;
-            const int xoff = h ? off1 : off0;
-            float av[MT], bv[NT];
+            if (s + 1 < C::KC / 2) {
+                const int k0 = 2 * (s + 1);
+                const int off0 = (k0 / KS) * C::XTP + (k0 % KS) * DIL;
+                const bool cross = ((k0 + 1) / KS) != (k0 / KS);
+                const float* xsp = cross ? xs_cross : xs_same;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[i] = wsrc[2 * s * C::BM + i * 32];
+                for (int i = 0; i < MT; ++i) av[(s + 1) & 1][i] = wsrc[2 * (s + 1) * C::BM + i * 32];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bv[j] = xsrc[xoff + j * 32 * STRIDE];
+                for (int j = 0; j < NT; ++j) bv[(s + 1) & 1][j] = xsp[off0 + j * 32 * STRIDE];
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
         }
     };
 
-    load_chunk(0);
-    store_chunk(0);
+    tile.load_chunk(0, wreg, xv, xs);
+    __syncthreads();                                  // alpha table visible
+    tile.store_chunk(0, 0, wreg, xv, xs);
     __syncthreads();
-    for (int c = 0; c < n_chunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < n_chunks) load_chunk(c + 1);
-        compute_chunk(buf);
-        if (c + 1 < n_chunks) store_chunk(buf ^ 1);
+    // steady state (no conditionals around the staging registers: loads of chunk c+1 stay in flight across the
+    // MFMAs of chunk c), last chunk peeled
+    for (int c = 0; c + 1 < n_chunks; ++c) {
+        tile.load_chunk(c + 1, wreg, xv, xs);
+        __builtin_amdgcn_sched_barrier(0);            // keep the loads ABOVE the MFMAs (the scheduler sinks them otherwise)
+        mfma_chunk(c & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        tile.store_chunk(c + 1, (c + 1) & 1, wreg, xv, xs);
         __syncthreads();
     }
+    mfma_chunk((n_chunks - 1) & 1);
 
-    // ---------------------------------------------------------------- epilogue
+    // ---------------------------------------------------------------- epilogue (branch-light: clamped
+    // addresses, one predicated store per element)
+    const bool has_res = !SHUFFLE && a.residual != nullptr;
+    const bool snake_out = a.alpha_out != nullptr;
+    const bool do_tanh = a.act == 1;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             const int m = m0 + (wm * MT + i) * 32 + row;
-            if (m >= a.Mrows) continue;
+            const bool mok = m < a.Mrows;
+            const int mc = mok ? m : a.Mrows - 1;
             int co, rr = 0;
-            if (SHUFFLE) { co = m / a.up_s; rr = m - co * a.up_s; } else { co = m; }
+            if (SHUFFLE) { co = mc / a.up_s; rr = mc - co * a.up_s; } else { co = mc; }
             const float bv = a.bias ? a.bias[co] : 0.0f;
-            float al = 0.0f, inv = 0.0f;
-            if (a.alpha_out) { al = a.alpha_out[co]; inv = 1.0f / (al + 1e-9f); }
+            float al = 1.0f, inv = 1.0f;
+            if (snake_out) { al = a.alpha_out[co]; inv = 1.0f / (al + 1e-9f); }
             const size_t rowoff = ((size_t)b * a.Cout + co) * a.Tout;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = n0 + (wn * NT + j) * 32 + l31;
-                if (n >= a.Ncols) continue;
-                int t;
-                if (SHUFFLE) { t = n * a.up_s + rr - a.up_p; if (t < 0 || t >= a.Tout) continue; } else { t = n; }
+                int t = SHUFFLE ? (n * a.up_s + rr - a.up_p) : n;
+                const bool ok = mok && n < a.Ncols && t >= 0 && t < a.Tout;
+                t = ok ? t : 0;
                 float v = acc[i][j][r] + bv;
-                if (!SHUFFLE && a.residual) v = v + a.residual[rowoff + t];
-                if (a.alpha_out) v = det_snake(v, al, inv);
-                if (a.act == 1) v = det_tanh(v);
-                a.y[rowoff + t] = v;
+                if (has_res) v = v + a.residual[rowoff + t];
+                if (snake_out) v = det_snake(v, al, inv);
+                if (do_tanh) v = det_tanh(v);
+                if (ok) a.y[rowoff + t] = v;
             }
         }
     }
+}
+
+// 16-byte input rows (Tin % 4 == 0) take the float4 staging path; the two paths are separate loop nests so that
+// no control-flow merge sits between a chunk's global loads and the MFMAs that hide them.
+template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE>
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a)
+{
+    if (a.vec4) conv1d_mfma_body<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE, true>(a);
+    else conv1d_mfma_body<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE, false>(a);
 }
 
 template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE>
@@ -221,17 +325,21 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
 {
     using C = ConvCfg<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE>;
     ConvArgs a = a_in;
+    if (a.Cin % CK != 0) return hipErrorInvalidValue;
     a.n_tiles = (a.Ncols + C::BN - 1) / C::BN;
+    a.vec4 = (a.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+    const size_t lds = (size_t)C::LDS_FLOATS * 4 + (a.alpha_in ? (size_t)2 * a.Cin * 4 : 0);
     auto kern = conv1d_mfma_kernel<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid((unsigned)(a.n_tiles * a.B), (unsigned)((a.Mrows + C::BM - 1) / C::BM));
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 

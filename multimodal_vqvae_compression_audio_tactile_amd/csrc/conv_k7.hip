@@ -6,7 +6,7 @@ static hipError_t k7(const ConvArgs& a, int bm, hipStream_t s)
 {
     switch (bm) {
         case 128: return launch_conv1d_mfma<7, 1, DIL, 8, 2, 2, 2, 2, false>(a, s);
-        case 96:  return launch_conv1d_mfma<7, 1, DIL, 8, 3, 2, 1, 4, false>(a, s);
+        case 96:  return launch_conv1d_mfma<7, 1, DIL, 8, 3, 1, 1, 4, false>(a, s);
         case 64:  return launch_conv1d_mfma<7, 1, DIL, 8, 2, 2, 1, 4, false>(a, s);
     }
     return hipErrorInvalidValue;

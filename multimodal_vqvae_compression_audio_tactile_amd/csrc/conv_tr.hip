@@ -6,7 +6,7 @@ hipError_t launch_conv_tr(const ConvArgs& a, int bm, hipStream_t s)
 {
     switch (bm) {
         case 128: return launch_conv1d_mfma<2, 1, 1, 32, 2, 2, 2, 2, true>(a, s);
-        case 96:  return launch_conv1d_mfma<2, 1, 1, 32, 3, 2, 1, 4, true>(a, s);
+        case 96:  return launch_conv1d_mfma<2, 1, 1, 32, 3, 1, 1, 4, true>(a, s);
         case 64:  return launch_conv1d_mfma<2, 1, 1, 32, 2, 2, 1, 4, true>(a, s);
     }
     return hipErrorInvalidValue;

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Per-layer timing of every conv shape on the path (HIP events, one GPU).  usage: conv_microbench.py [B] [filter]"""
+import math, sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+from multimodal_vqvae_compression_audio_tactile_amd import ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+flt = sys.argv[2] if len(sys.argv) > 2 else ""
+dev = torch.device("cuda:0")
+layers = []   # (name, kind, Cin, Cout, ks, stride, dil, Tin, alpha_in, residual, alpha_out, count)
+def ru(prefix, C, T, n):
+    for d in (1, 3, 9):
+        layers.append((f"{prefix}.k7d{d}", "c", C, C, 7, 1, d, T, True, False, True, n))
+    layers.append((f"{prefix}.k1", "c", C, C, 1, 1, 1, T, False, True, False, 3 * n))
+T = 24000; C = 64
+for i, s in enumerate((2, 4, 5, 8)):
+    ru(f"enc.b{i}", C, T, 2)
+    layers.append((f"enc.b{i}.down", "c", C, 2 * C, 2 * s, s, 1, T, False, False, False, 2))
+    T //= s; C *= 2
+layers.append(("enc.out.k3", "c", 1024, 1024, 3, 1, 1, 75, False, False, False, 2))
+layers.append(("dec.in.k7", "c", 1024, 1536, 7, 1, 1, 75, False, False, True, 1))
+T = 75; C = 1536
+for i, s in enumerate((8, 5, 4, 2)):
+    layers.append((f"dec.b{i}.up", "t", C, C // 2, 2 * s, s, 1, T, False, False, False, 1))
+    T = (T - 1) * s - 2 * math.ceil(s / 2) + 2 * s; C //= 2
+    ru(f"dec.b{i}", C, T, 1)
+layers.append(("pred.linear1024", "f", 1024, 1024, 1, 1, 1, 16, False, False, False, 20))
+layers.append(("pred.ffn1", "f", 1024, 2048, 1, 1, 1, 16, False, False, False, 5))
+layers.append(("pred.ffn3", "f", 2048, 1024, 1, 1, 1, 16, False, True, False, 5))
+layers.append(("proj_down", "f", 1024, 96, 1, 1, 1, 16, False, False, False, 5))
+layers.append(("proj_up", "f", 96, 1024, 1, 1, 1, 16, False, True, False, 5))
+
+tot = 0.0
+print(f"B={B}")
+for (name, kind, cin, cout, ks, st, dil, tin, ai, res, ao, count) in layers:
+    if flt and flt not in name: continue
+    if kind == "f":
+        x = torch.randn(1, cin, B * tin, device=dev)
+    else:
+        x = torch.randn(B, cin, tin, device=dev)
+    Bx, _, Tx = x.shape
+    if kind == "t":
+        w = torch.randn(cin, cout, ks, device=dev) / math.sqrt(cin * 2)
+        wp = ops.pack_conv_transpose1d(w, st)
+        f = lambda: ops.conv_transpose1d(x, wp, cout, st, math.ceil(st / 2))
+        flops = 2.0 * cin * cout * ks * Tx * Bx
+        kname = ops.conv_kernel_name(cin, cout, ks, st, 1, True)
+    else:
+        w = torch.randn(cout, cin, ks, device=dev) / math.sqrt(cin * ks)
+        wp = ops.pack_conv1d(w)
+        pad = (ks - 1) * dil // 2 if st == 1 else math.ceil(st / 2)
+        tout = ops.conv1d_out_len(Tx, ks, st, dil, pad)
+        a_in = torch.rand(cin, device=dev) + 0.5 if ai else None
+        a_out = torch.rand(cout, device=dev) + 0.5 if ao else None
+        r = torch.randn(Bx, cout, tout, device=dev) if res else None
+        bias = torch.randn(cout, device=dev)
+        f = lambda: ops.conv1d(x, wp, cout, ks, bias=bias, stride=st, dil=dil, pad=pad, alpha_in=a_in, residual=r, alpha_out=a_out)
+        flops = 2.0 * cin * cout * ks * tout * Bx
+        kname = ops.conv_kernel_name(cin, cout, ks, st, dil)
+    f(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    n = 5
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    tot += ms * count
+    print(f"{name:18s} {kname[18:60]:42s} Cin {cin:5d} Cout {cout:5d} T {Tx:7d} {ms:8.3f} ms x{count:2d} = {ms*count:7.2f} ms  {flops/ms*1e-9:6.1f} TF")
+print(f"sum over path: {tot:.1f} ms per step")
