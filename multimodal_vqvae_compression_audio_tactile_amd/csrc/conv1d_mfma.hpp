@@ -43,6 +43,7 @@ struct ConvArgs {
     int act;
     int up_s, up_p;         // SHUFFLE: stride S and torch padding P
     int vec4;               // input rows are 16-byte aligned (Tin % 4 == 0 and x 16-byte aligned)
+    int ovec4;              // output (and residual) rows are 16-byte aligned (Tout % 4 == 0, pointers aligned)
 };
 
 template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE>
@@ -55,7 +56,10 @@ struct ConvCfg {
     static constexpr int XTP = XV * 4 + 4;                               // row pitch (floats), multiple of 4
     static constexpr int W_FLOATS = KC * BM;
     static constexpr int X_FLOATS = CK * XTP;
-    static constexpr int LDS_FLOATS = 2 * (W_FLOATS + X_FLOATS);
+    static constexpr int STAGE_FLOATS = 2 * (W_FLOATS + X_FLOATS);
+    static constexpr int BNP = BN + 4;                                   // pitch of the epilogue tile
+    static constexpr int CT_FLOATS = BM * BNP;
+    static constexpr int LDS_FLOATS = STAGE_FLOATS > CT_FLOATS ? STAGE_FLOATS : CT_FLOATS;
     static constexpr int W_VEC = W_FLOATS / 4;                           // float4 per chunk
     static constexpr int W_PER_THREAD = (W_VEC + 255) / 256;
     static constexpr int XV_TOTAL = CK * XV;
@@ -276,36 +280,116 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     }
     mfma_chunk((n_chunks - 1) & 1);
 
-    // ---------------------------------------------------------------- epilogue (branch-light: clamped
-    // addresses, one predicated store per element)
+    // ---------------------------------------------------------------- epilogue
+    // The accumulators go through LDS once (the staging buffers are free now) so that bias / residual / Snake /
+    // tanh and the global stores run row-contiguous: 16-byte residual loads and stores when rows are aligned,
+    // 4-byte but fully coalesced otherwise.  (ConvTranspose phases whose count does not divide BM keep the
+    // direct per-lane store.)
     const bool has_res = !SHUFFLE && a.residual != nullptr;
     const bool snake_out = a.alpha_out != nullptr;
     const bool do_tanh = a.act == 1;
+    const bool direct = SHUFFLE && (C::BM % a.up_s != 0);
+    if (direct) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = m0 + (wm * MT + i) * 32 + row;
+                const bool mok = m < a.Mrows;
+                const int mc = mok ? m : a.Mrows - 1;
+                const int co = mc / a.up_s, rr = mc - co * a.up_s;
+                const float bv = a.bias ? a.bias[co] : 0.0f;
+                float al = 1.0f, inv = 1.0f;
+                if (snake_out) { al = a.alpha_out[co]; inv = 1.0f / (al + 1e-9f); }
+                const size_t rowoff = ((size_t)b * a.Cout + co) * a.Tout;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int n = n0 + (wn * NT + j) * 32 + l31;
+                    int t = n * a.up_s + rr - a.up_p;
+                    const bool ok = mok && n < a.Ncols && t >= 0 && t < a.Tout;
+                    t = ok ? t : 0;
+                    float v = acc[i][j][r] + bv;
+                    if (snake_out) v = det_snake(v, al, inv);
+                    if (ok) a.y[rowoff + t] = v;
+                }
+            }
+        }
+        return;
+    }
+
+    float* const Ct = smem;                          // [BM][BNP]
+    __syncthreads();                                  // every wave is done with the staging buffers
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int m = m0 + (wm * MT + i) * 32 + row;
-            const bool mok = m < a.Mrows;
-            const int mc = mok ? m : a.Mrows - 1;
-            int co, rr = 0;
-            if (SHUFFLE) { co = mc / a.up_s; rr = mc - co * a.up_s; } else { co = mc; }
-            const float bv = a.bias ? a.bias[co] : 0.0f;
-            float al = 1.0f, inv = 1.0f;
-            if (snake_out) { al = a.alpha_out[co]; inv = 1.0f / (al + 1e-9f); }
-            const size_t rowoff = ((size_t)b * a.Cout + co) * a.Tout;
+            const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = n0 + (wn * NT + j) * 32 + l31;
-                int t = SHUFFLE ? (n * a.up_s + rr - a.up_p) : n;
-                const bool ok = mok && n < a.Ncols && t >= 0 && t < a.Tout;
-                t = ok ? t : 0;
-                float v = acc[i][j][r] + bv;
-                if (has_res) v = v + a.residual[rowoff + t];
-                if (snake_out) v = det_snake(v, al, inv);
-                if (do_tanh) v = det_tanh(v);
-                if (ok) a.y[rowoff + t] = v;
+            for (int j = 0; j < NT; ++j) Ct[row * C::BNP + (wn * NT + j) * 32 + l31] = acc[i][j][r];
+        }
+    __syncthreads();
+
+    if (!SHUFFLE) {
+        if (a.ovec4) {
+            constexpr int NV = C::BM * C::BN / 4;
+#pragma unroll 4
+            for (int e = tid; e < NV; e += 256) {
+                const int row = e / (C::BN / 4);
+                const int c4 = e - row * (C::BN / 4);
+                const int m = m0 + row, n = n0 + 4 * c4;
+                if (m < a.Mrows && n < a.Ncols) {
+                    const float bv = a.bias ? a.bias[m] : 0.0f;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(Ct + row * C::BNP + 4 * c4);
+                    const size_t off = ((size_t)b * a.Cout + m) * a.Tout + n;
+                    v.x = v.x + bv; v.y = v.y + bv; v.z = v.z + bv; v.w = v.w + bv;
+                    if (has_res) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(a.residual + off);
+                        v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
+                    }
+                    if (snake_out) {
+                        const float al = a.alpha_out[m], inv = 1.0f / (al + 1e-9f);
+                        v.x = det_snake(v.x, al, inv); v.y = det_snake(v.y, al, inv);
+                        v.z = det_snake(v.z, al, inv); v.w = det_snake(v.w, al, inv);
+                    }
+                    if (do_tanh) { v.x = det_tanh(v.x); v.y = det_tanh(v.y); v.z = det_tanh(v.z); v.w = det_tanh(v.w); }
+                    *reinterpret_cast<f32x4*>(a.y + off) = v;
+                }
+            }
+        } else {
+            constexpr int NE = C::BM * C::BN;
+#pragma unroll 4
+            for (int e = tid; e < NE; e += 256) {
+                const int row = e / C::BN;
+                const int col = e - row * C::BN;
+                const int m = m0 + row, n = n0 + col;
+                if (m < a.Mrows && n < a.Ncols) {
+                    const size_t off = ((size_t)b * a.Cout + m) * a.Tout + n;
+                    float v = Ct[row * C::BNP + col] + (a.bias ? a.bias[m] : 0.0f);
+                    if (has_res) v = v + a.residual[off];
+                    if (snake_out) { const float al = a.alpha_out[m]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
+                    if (do_tanh) v = det_tanh(v);
+                    a.y[off] = v;
+                }
+            }
+        }
+    } else {
+        // pixel shuffle: for each output channel of this tile the S phases interleave into one contiguous run
+        const int S = a.up_s;
+        const int run = C::BN * S;                    // output samples per channel covered by this tile
+        const int nco = C::BM / S;
+        const int t_base = n0 * S - a.up_p;
+        const int total = nco * run;
+        for (int e = tid; e < total; e += 256) {
+            const int col = e / run;
+            const int tl = e - col * run;
+            const int nl = tl / S, rr = tl - nl * S;
+            const int co = m0 / S + col;
+            const int t = t_base + tl;
+            if (co < a.Cout && n0 + nl < a.Ncols && t >= 0 && t < a.Tout) {
+                float v = Ct[(col * S + rr) * C::BNP + nl] + (a.bias ? a.bias[co] : 0.0f);
+                if (snake_out) { const float al = a.alpha_out[co]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
+                a.y[((size_t)b * a.Cout + co) * a.Tout + t] = v;
             }
         }
     }
@@ -328,6 +412,8 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
     if (a.Cin % CK != 0) return hipErrorInvalidValue;
     a.n_tiles = (a.Ncols + C::BN - 1) / C::BN;
     a.vec4 = (a.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+    a.ovec4 = (a.Tout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
+              (!a.residual || (reinterpret_cast<uintptr_t>(a.residual) & 15) == 0);
     const size_t lds = (size_t)C::LDS_FLOATS * 4 + (a.alpha_in ? (size_t)2 * a.Cin * 4 : 0);
     auto kern = conv1d_mfma_kernel<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE>;
     static bool attr_set = false;

@@ -165,9 +165,57 @@ hipError_t launch_convtr_direct(const DirectConvArgs& a, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm over C of channel-major x[B,C,T] (+ optional positional-encoding add, tanh, scale).
-// One thread per token; lanes = consecutive t (coalesced); channel loop sequential (the contract).
+// LayerNorm over C of channel-major x (+ optional positional-encoding add, tanh, scale); element (b,c,t) at
+// b*sb + c*sc + t.  The contract fixes the reduction order (channel ascending, sequential), so a block stages a
+// [C][32-token] tile in LDS with coalesced loads, 32 threads walk their token's channel column out of LDS
+// (conflict-free: lane = token), and all 256 threads normalise and store coalesced.
+// Fallback (C too large for LDS): one thread per token straight from global memory.
 // ------------------------------------------------------------------------------------------------
+constexpr int LN_TOK = 32;
+
+__global__ __launch_bounds__(256) void layernorm_c_tile_kernel(
+    const float* __restrict__ x, const float* __restrict__ pe, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ y, int B, int C, int T, size_t sb, size_t sc,
+    float eps, int do_tanh, float post_scale)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [C][LN_TOK] | mean[LN_TOK] | rstd[LN_TOK]
+    float* mean_s = tile + (size_t)C * LN_TOK;
+    float* rstd_s = mean_s + LN_TOK;
+    const int tid = threadIdx.x;
+    const int tok = tid & (LN_TOK - 1);
+    const int cg = tid / LN_TOK;                                       // 0..7
+    const int n = blockIdx.x * LN_TOK + tok;
+    const bool live = n < B * T;
+    const int b = live ? n / T : 0, t = live ? n - b * T : 0;
+    const float* xb = x + (size_t)b * sb + t;
+    const float* per = pe ? pe + (size_t)t * C : nullptr;
+    for (int c = cg; c < C; c += 256 / LN_TOK) {
+        float v = 0.0f;
+        if (live) { v = xb[(size_t)c * sc]; if (per) v = v + per[c]; }
+        tile[c * LN_TOK + tok] = v;
+    }
+    __syncthreads();
+    if (tid < LN_TOK) {
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) s = s + tile[c * LN_TOK + tid];
+        const float mean = s / (float)C;
+        float var = 0.0f;
+        for (int c = 0; c < C; ++c) { const float d = tile[c * LN_TOK + tid] - mean; var = dfma(d, d, var); }
+        mean_s[tid] = mean;
+        rstd_s[tid] = 1.0f / __builtin_sqrtf(var / (float)C + eps);
+    }
+    __syncthreads();
+    if (!live) return;
+    const float mean = mean_s[tok], rstd = rstd_s[tok];
+    float* yb = y + (size_t)b * sb + t;
+    for (int c = cg; c < C; c += 256 / LN_TOK) {
+        float o = dfma((tile[c * LN_TOK + tok] - mean) * rstd, gamma[c], beta[c]);
+        if (do_tanh) o = det_tanh(o);
+        if (do_tanh || post_scale != 1.0f) o = post_scale * o;
+        yb[(size_t)c * sc] = o;
+    }
+}
+
 __global__ void layernorm_c_kernel(const float* __restrict__ x, const float* __restrict__ pe,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ y, int B, int C, int T, size_t sb, size_t sc,
@@ -210,8 +258,21 @@ hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamm
 {
     const int n = B * T;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(layernorm_c_kernel, dim3((n + 63) / 64), dim3(64), 0, s, x, pe, gamma, beta, y, B, C, T, sb, sc,
-                       eps, do_tanh, post_scale);
+    const size_t lds = ((size_t)C * LN_TOK + 2 * LN_TOK) * sizeof(float);
+    if (lds <= 160 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_c_tile_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr = true;
+        }
+        hipLaunchKernelGGL(layernorm_c_tile_kernel, dim3((n + LN_TOK - 1) / LN_TOK), dim3(256), lds, s,
+                           x, pe, gamma, beta, y, B, C, T, sb, sc, eps, do_tanh, post_scale);
+    } else {
+        hipLaunchKernelGGL(layernorm_c_kernel, dim3((n + 63) / 64), dim3(64), 0, s, x, pe, gamma, beta, y, B, C, T, sb, sc,
+                           eps, do_tanh, post_scale);
+    }
     return hipGetLastError();
 }
 

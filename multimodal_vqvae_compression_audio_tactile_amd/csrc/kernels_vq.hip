@@ -3,7 +3,7 @@
 //  (1) rvq_ema_forward: the reference's own ResidualVQEMA (K <= 512, D = 96): argmax_k(res.e_k - 0.5||e_k||^2)
 //      per book with the residual carried between books.  One block owns TOKS tokens for ALL books; per book the
 //      codebook is pinned in LDS (transposed [D][K] image, at most 256 codes at a time = 96 KiB for D = 96), every
-//      lane scores its own codes for 4 tokens at once and the per-token winner is a wavefront arg-max reduction
+//      lane scores its own codes for the wave's 2 tokens at once and the per-token winner is a wavefront arg-max reduction
 //      (lowest index on ties, like torch.argmax on CPU).
 //  (2) rvq_assign / ema_update: ResidualVQEMA.ema_step (deterministic token-order sums).
 //  (3) dac_rvq: the 32-stage DAC residual quantiser (K = 1024, Dc = 8) fused into ONE launch: in_proj, L2
@@ -32,7 +32,27 @@ __device__ __forceinline__ void wave_argmax(float& s, int& i)
     }
 }
 
-constexpr int RVQ_TOKS = 32;     // tokens per block
+// dst[0..n) = src[0..n) with 8 x 16-byte loads in flight per thread (n % 4 == 0, both 16-byte aligned)
+__device__ __forceinline__ void copy_to_lds_f4(float* dst, const float* __restrict__ src, int n, int tid)
+{
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const int nvec = n >> 2;
+    for (int base = 0; base < nvec; base += 256 * 8) {
+        v4 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + tid;
+            r[u] = *reinterpret_cast<const v4*>(src + 4 * (size_t)(i < nvec ? i : nvec - 1));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + tid;
+            if (i < nvec) *reinterpret_cast<v4*>(dst + 4 * (size_t)i) = r[u];
+        }
+    }
+}
+
+constexpr int RVQ_TOKS = 8;      // tokens per block (2 per wave)
 constexpr int RVQ_KH = 256;      // codes resident in LDS at a time
 
 // LDS: Et[D][KH+1] | hn[KH] | resT[D][TOKS] | qsT[D][TOKS] | best_s[TOKS] | best_i[TOKS]
@@ -69,9 +89,28 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_kernel(
             const int kh = K - k0 < RVQ_KH ? K - k0 : RVQ_KH;
             __syncthreads();
             // stage transposed codebook slice: global row-major (coalesced) -> Et[d][k] (odd pitch: conflict-free)
-            for (int i = tid; i < kh * D; i += 256) {
-                const int k = i / D, d = i - k * D;
-                Et[d * KHP + k] = emb[(size_t)(k0 + k) * D + d];
+            {
+                typedef float v4 __attribute__((ext_vector_type(4)));
+                const int dv = D >> 2;                                  // float4 per code row (D % 4 == 0)
+                const int nvec = kh * dv;
+                const float* src = emb + (size_t)k0 * D;
+                for (int base = 0; base < nvec; base += 256 * 8) {
+                    v4 r[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = base + u * 256 + tid;
+                        r[u] = *reinterpret_cast<const v4*>(src + 4 * (size_t)(i < nvec ? i : nvec - 1));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = base + u * 256 + tid;
+                        if (i < nvec) {
+                            const int k = i / dv, d4 = (i - k * dv) * 4;
+                            Et[(d4 + 0) * KHP + k] = r[u].x; Et[(d4 + 1) * KHP + k] = r[u].y;
+                            Et[(d4 + 2) * KHP + k] = r[u].z; Et[(d4 + 3) * KHP + k] = r[u].w;
+                        }
+                    }
+                }
             }
             __syncthreads();
             for (int k = tid; k < kh; k += 256) {
@@ -80,31 +119,27 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_kernel(
                 hn[k] = 0.5f * s;
             }
             __syncthreads();
-            // each wave scores 8 tokens, 4 at a time
-            for (int g = 0; g < RVQ_TOKS / 4 / 4; ++g) {
-                const int tok0 = wave * (RVQ_TOKS / 4) + g * 4;
-                float bs[4]; int bi[4];
+            // each wave scores its 2 tokens against the resident codes (lane = code)
+            {
+                const int tok0 = wave * 2;
+                float bs[2]; int bi[2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { bs[u] = -__builtin_inff(); bi[u] = 0x7fffffff; }
+                for (int u = 0; u < 2; ++u) { bs[u] = -__builtin_inff(); bi[u] = 0x7fffffff; }
                 for (int kk = lane; kk < kh; kk += 64) {
-                    float dot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    float dot0 = 0.0f, dot1 = 0.0f;
                     for (int d = 0; d < D; ++d) {
                         const float e = Et[d * KHP + kk];
-                        const float4 r = *reinterpret_cast<const float4*>(resT + d * RVQ_TOKS + tok0);
-                        dot[0] = dfma(r.x, e, dot[0]);
-                        dot[1] = dfma(r.y, e, dot[1]);
-                        dot[2] = dfma(r.z, e, dot[2]);
-                        dot[3] = dfma(r.w, e, dot[3]);
+                        const float2 r = *reinterpret_cast<const float2*>(resT + d * RVQ_TOKS + tok0);
+                        dot0 = dfma(r.x, e, dot0);
+                        dot1 = dfma(r.y, e, dot1);
                     }
                     const float h = hn[kk];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float sc = dot[u] - h;
-                        if (sc > bs[u]) { bs[u] = sc; bi[u] = k0 + kk; }
-                    }
+                    const float sc0 = dot0 - h, sc1 = dot1 - h;
+                    if (sc0 > bs[0]) { bs[0] = sc0; bi[0] = k0 + kk; }
+                    if (sc1 > bs[1]) { bs[1] = sc1; bi[1] = k0 + kk; }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2; ++u) {
                     wave_argmax(bs[u], bi[u]);
                     if (lane == 0) {
                         if (k0 == 0) { best_s[tok0 + u] = bs[u]; best_i[tok0 + u] = bi[u]; }
@@ -202,7 +237,7 @@ hipError_t launch_ema_update(const float* z, const int32_t* idx, float* books, i
 
 // ------------------------------------------------------------------------------------------------
 // DAC residual VQ, all stages fused.  Block = 256 threads, 16 tokens.
-//   LDS: res[C][16] | cbn[K][Dc] | cn2[K] | ze[Dc][16] | e[Dc][16] | pre[Dc][16] | red_s[16][16] | red_i[16][16]
+//   LDS: res[C][16] | cbn[K][Dc] | cn2[K] | ze[Dc][16] | e[Dc][16] | pre[Dc][16] | red_s[16][16] | red_i[16][16] | w[Dc*C]
 // ------------------------------------------------------------------------------------------------
 constexpr int DQ_TOK = 16;
 
@@ -222,6 +257,7 @@ __global__ __launch_bounds__(256) void dac_rvq_kernel(
     float* en2 = pre + Dc * DQ_TOK;                    // [16]
     float* red_s = en2 + DQ_TOK;                       // [16 groups][16 tok]
     int* red_i = reinterpret_cast<int*>(red_s + 16 * DQ_TOK);
+    float* wst = reinterpret_cast<float*>(red_i + 16 * DQ_TOK);   // [Dc*C]: in_proj weights, then out_proj weights
 
     const int tid = threadIdx.x;
     const int tok = tid & 15;
@@ -244,19 +280,24 @@ __global__ __launch_bounds__(256) void dac_rvq_kernel(
 
     for (int st = 0; st < nq; ++st) {
         __syncthreads();
-        // normalised codebook of this stage
+        // normalised codebook of this stage: raw rows -> LDS (batched 16-byte loads), then normalise in place
         const float* cbs = cb + (size_t)st * K * Dc;
+        copy_to_lds_f4(cbn, cbs, K * Dc, tid);
+        __syncthreads();
         for (int k = tid; k < K; k += 256) {
             float ss = 0.0f;
-            for (int d = 0; d < Dc; ++d) { const float v = cbs[(size_t)k * Dc + d]; ss = dfma(v, v, ss); }
+            for (int d = 0; d < Dc; ++d) { const float v = cbn[k * Dc + d]; ss = dfma(v, v, ss); }
             const float den = __builtin_fmaxf(__builtin_sqrtf(ss), 1e-12f);
             float s2 = 0.0f;
-            for (int d = 0; d < Dc; ++d) { const float v = cbs[(size_t)k * Dc + d] / den; cbn[k * Dc + d] = v; s2 = dfma(v, v, s2); }
+            for (int d = 0; d < Dc; ++d) { const float v = cbn[k * Dc + d] / den; cbn[k * Dc + d] = v; s2 = dfma(v, v, s2); }
             cn2[k] = s2;
         }
+        // stage this stage's in_proj weights [Dc][C] in LDS (a chain fed by global loads runs at memory latency)
+        copy_to_lds_f4(wst, in_w + (size_t)st * Dc * C, Dc * C, tid);
+        __syncthreads();
         // in_proj: thread (d = grp < Dc, tok): chain over C
         if (grp < Dc) {
-            const float* wr = in_w + ((size_t)st * Dc + grp) * C;
+            const float* wr = wst + (size_t)grp * C;
             float a = 0.0f;
             for (int c = 0; c < C; ++c) a = dfma(wr[c], res[c * DQ_TOK + tok], a);
             const float v = a + in_b[(size_t)st * Dc + grp];
@@ -264,7 +305,9 @@ __global__ __launch_bounds__(256) void dac_rvq_kernel(
             if (live) latents[((size_t)bb * nq * Dc + (size_t)st * Dc + grp) * T + tt] = v;
         }
         __syncthreads();
-        // F.normalize over Dc (every thread of a token computes the same values; grp 0 publishes)
+        // out_proj weights [C][Dc] replace the in_proj weights in LDS (used after the search)
+        copy_to_lds_f4(wst, out_w + (size_t)st * C * Dc, Dc * C, tid);
+        // F.normalize over Dc (every thread of a token computes the same values)
         {
             float ss = 0.0f;
             for (int d = 0; d < Dc; ++d) { const float v = ze[d * DQ_TOK + tok]; ss = dfma(v, v, ss); }
@@ -302,7 +345,7 @@ __global__ __launch_bounds__(256) void dac_rvq_kernel(
             float pv[16];
 #pragma unroll
             for (int d = 0; d < 16; ++d) if (d < Dc) pv[d] = pre[d * DQ_TOK + tok];
-            const float* ow = out_w + (size_t)st * C * Dc;
+            const float* ow = wst;
             const float* ob = out_b + (size_t)st * C;
 #pragma unroll
             for (int j = 0; j < 64; ++j) {
@@ -332,7 +375,7 @@ hipError_t launch_dac_rvq(const float* z, const float* in_w, const float* in_b, 
 {
     const int N = B * T;
     if (N == 0) return hipSuccess;
-    const size_t lds = ((size_t)C * DQ_TOK + (size_t)K * Dc + K + 3 * (size_t)Dc * DQ_TOK + DQ_TOK + 2 * 16 * DQ_TOK) * sizeof(float);
+    const size_t lds = ((size_t)C * DQ_TOK + (size_t)K * Dc + K + 3 * (size_t)Dc * DQ_TOK + DQ_TOK + 2 * 16 * DQ_TOK + (size_t)Dc * C) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dac_rvq_kernel),
