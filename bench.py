@@ -9,7 +9,7 @@ HBM: ProposedEval.forward_eval (A_ENC + 32-book A_QUANT + T_ENC + 5 AR chunks wi
 data-path collective ("weak" scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     -- the dominant kernel (largest share of device time among conv1d_mfma instantiations): algorithmic
+  roofline     -- the dominant kernel (largest share of device time among the conv / residual-unit kernel instantiations): algorithmic
                   FLOPs per launch / its average duration measured with HIP events on the launch stream during the
                   timed steps, against the fp32 MFMA peak (157.3 TFLOP/s).
   cpu_baseline -- the torch-CPU restatement of the same path (oracle/dac24_torch.py, "port") timed on this node's
@@ -56,8 +56,17 @@ class KernelEvents:
         self.records = []
 
     def wrap(self, ops):
-        orig_conv, orig_tr = ops.conv1d, ops.conv_transpose1d
+        orig_conv, orig_tr, orig_ru = ops.conv1d, ops.conv_transpose1d, ops.residual_unit_fused
         rec = self.records
+
+        def residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None):
+            B, c, t = x.shape
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig_ru(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next)
+            e1.record()
+            rec.append((ops.residual_unit_kernel_name(c, dil), 2.0 * c * c * 8 * t * B, e0, e1))
+            return y
 
         def conv1d(x, wp, cout, ks, bias=None, stride=1, dil=1, pad=0, **kw):
             B, cin, tin = x.shape
@@ -79,8 +88,9 @@ class KernelEvents:
                         2.0 * cin * cout * 2 * stride * tin * B, e0, e1))
             return y
 
-        ops.conv1d, ops.conv_transpose1d = conv1d, conv_transpose1d
-        self._restore = lambda: (setattr(ops, "conv1d", orig_conv), setattr(ops, "conv_transpose1d", orig_tr))
+        ops.conv1d, ops.conv_transpose1d, ops.residual_unit_fused = conv1d, conv_transpose1d, residual_unit_fused
+        self._restore = lambda: (setattr(ops, "conv1d", orig_conv), setattr(ops, "conv_transpose1d", orig_tr),
+                                 setattr(ops, "residual_unit_fused", orig_ru))
 
     def summary(self):
         tot = defaultdict(lambda: [0.0, 0.0, 0])

@@ -76,6 +76,17 @@ int mvq_conv1d_f32(const float* x, const float* wp, const float* bias, const flo
  * For transposed convs pass the torch shape (cin, cout, ks = 2*stride, stride). */
 int mvq_conv_kernel_name(int cin, int cout, int ks, int stride, int dil, int transposed, char* buf, int len);
 
+/* One upstream dac ResidualUnit:  y = snake_next?( x + conv1( snake_b( conv7_dil( snake_a(x) ) + b7 ) ) + b1 ),
+ * 7-tap conv with dilation `dil` and padding 3*dil, then a 1x1 conv, both C -> C.  For C in {64, 96, 128} (the
+ * high-rate ends of the stacks, where the 1x1 conv is bandwidth-bound on its own) the whole unit is ONE launch and
+ * the intermediate never leaves the CU; otherwise two launches through `scratch` (B*C*T floats, see
+ * mvq_residual_unit_scratch_floats; may be NULL when that returns 0).  alpha_next: the following Snake1d or NULL. */
+size_t mvq_residual_unit_scratch_floats(int batch, int c, int t, int dil);
+int mvq_residual_unit_kernel_name(int c, int dil, char* buf, int len);   /* "residual_unit_kernel<...>" or "(two launches)" */
+int mvq_residual_unit_f32(const float* x, const float* w7p, const float* b7, const float* alpha_a,
+                          const float* alpha_b, const float* w1p, const float* b1, const float* alpha_next,
+                          float* y, float* scratch, int batch, int c, int t, int dil, void* stream);
+
 /* y = snake_out( conv_transpose1d( snake_in(x) ) + bias ), kernel = 2*stride, torch `padding` = pad.
  * Replaces the Snake1d + WNConvTranspose1d at the head of every upstream DecoderBlock.
  *   Tout = (Tin-1)*stride - 2*pad + 2*stride. */

@@ -136,6 +136,48 @@ int mvq_conv1d_f32(const float* x, const float* wp, const float* bias, const flo
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d");
 }
 
+static bool ru_fusable(int c, int dil)
+{
+    return (c == 64 || c == 96 || c == 128) && (dil == 1 || dil == 3 || dil == 9);
+}
+
+int mvq_residual_unit_kernel_name(int c, int dil, char* buf, int len)
+{
+    if (!buf || len <= 0) return fail(MVQ_EINVAL, "residual_unit_kernel_name: bad buffer");
+    if (!ru_fusable(c, dil)) { snprintf(buf, len, "%s", "(two launches)"); return MVQ_OK; }
+    const char* tile = c == 128 ? "2, 2, 2, 2" : (c == 96 ? "3, 1, 1, 4" : "2, 2, 1, 4");
+    snprintf(buf, len, "residual_unit_kernel<%d, 8, %s>", dil, tile);
+    return MVQ_OK;
+}
+
+size_t mvq_residual_unit_scratch_floats(int batch, int c, int t, int dil)
+{
+    if (batch <= 0 || c <= 0 || t <= 0) return 0;
+    return ru_fusable(c, dil) ? 0 : (size_t)batch * c * t;
+}
+
+int mvq_residual_unit_f32(const float* x, const float* w7p, const float* b7, const float* alpha_a,
+                          const float* alpha_b, const float* w1p, const float* b1, const float* alpha_next,
+                          float* y, float* scratch, int batch, int c, int t, int dil, void* stream)
+{
+    if (batch < 0 || c <= 0 || t < 0 || dil <= 0) return fail(MVQ_EINVAL, "residual_unit: bad shape");
+    if (batch == 0 || t == 0) return MVQ_OK;
+    if (!x || !w7p || !w1p || !alpha_a || !alpha_b || !y) return fail(MVQ_EINVAL, "residual_unit: null tensor");
+    if (ru_fusable(c, dil)) {
+        mvq::ConvArgs a{};
+        a.x = x; a.wp = w7p; a.bias = b7; a.alpha_in = alpha_a; a.residual = x; a.alpha_out = alpha_next; a.y = y;
+        a.B = batch; a.Cin = c; a.Tin = t; a.Cout = c; a.Tout = t; a.pad = 3 * dil; a.Mpad = mvq::conv_mpad(c);
+        a.Mrows = c; a.Ncols = t; a.act = 0; a.up_s = 1; a.up_p = 0;
+        a.alpha_mid = alpha_b; a.w2p = w1p; a.bias2 = b1;
+        hipError_t e = mvq::launch_residual_unit_fused(a, dil, S(stream));
+        return e == hipSuccess ? MVQ_OK : hipfail(e, "residual_unit(fused)");
+    }
+    if (!scratch) return fail(MVQ_EINVAL, "residual_unit: scratch required for C=%d (see mvq_residual_unit_scratch_floats)", c);
+    int rc = mvq_conv1d_f32(x, w7p, b7, alpha_a, nullptr, alpha_b, scratch, batch, c, t, c, 7, 1, dil, 3 * dil, MVQ_ACT_NONE, stream);
+    if (rc != MVQ_OK) return rc;
+    return mvq_conv1d_f32(scratch, w1p, b1, nullptr, x, alpha_next, y, batch, c, t, c, 1, 1, 1, 0, MVQ_ACT_NONE, stream);
+}
+
 int mvq_conv_transpose1d_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
                              const float* alpha_out, float* y,
                              int batch, int cin, int tin, int cout, int stride, int pad, void* stream)

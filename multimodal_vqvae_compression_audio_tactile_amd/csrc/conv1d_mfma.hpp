@@ -44,6 +44,10 @@ struct ConvArgs {
     int up_s, up_p;         // SHUFFLE: stride S and torch padding P
     int vec4;               // input rows are 16-byte aligned (Tin % 4 == 0 and x 16-byte aligned)
     int ovec4;              // output (and residual) rows are 16-byte aligned (Tout % 4 == 0, pointers aligned)
+    // fused ResidualUnit (FUSE kernels): y = x + conv1(snake_mid(conv7(snake_in(x)) + bias) ) + bias2, then alpha_out
+    const float* alpha_mid; // [C] Snake between the two convs
+    const float* w2p;       // packed 1x1 weights [(c) * Mpad + co]
+    const float* bias2;     // [C] or null
 };
 
 template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE>
@@ -170,7 +174,7 @@ struct ConvTile {
     }
 };
 
-template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE, bool VEC>
+template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE, bool VEC, bool FUSE>
 __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
 {
     using C = ConvCfg<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE>;
@@ -198,6 +202,18 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     const int n_chunks = Cin / CK;
     const bool snake_in = a.alpha_in != nullptr;
 
+#ifdef MVQ_STAGGER
+    // Two blocks share a CU (one wave each per SIMD) and run the same program: started together they stay in
+    // lock-step (both staging, then both fighting for the matrix pipe).  The block whose wave 0 sits in an odd
+    // wave slot starts a fraction of a chunk later, which de-phases the pair for the whole run.
+    {
+        if (tid == 0) reinterpret_cast<int*>(smem)[0] = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u);
+        __syncthreads();
+        const int odd = reinterpret_cast<volatile int*>(smem)[0];
+        __syncthreads();
+        if (odd) { for (int i = 0; i < MVQ_STAGGER; ++i) __builtin_amdgcn_s_sleep(64); }
+    }
+#endif
     if (snake_in) {
         for (int c = tid; c < Cin; c += 256) {
             const float al = a.alpha_in[c];
@@ -261,6 +277,11 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
+#ifdef MVQ_SCHED_GROUPS
+            // operand reads of step s+1 first, then the MFMAs of step s (keeps a full k-step of latency cover)
+            __builtin_amdgcn_sched_group_barrier(0x100, MVQ_SCHED_GROUPS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+#endif
         }
     };
 
@@ -279,6 +300,64 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         __syncthreads();
     }
     mfma_chunk((n_chunks - 1) & 1);
+
+    // ---------------------------------------------------------------- fused ResidualUnit tail (FUSE)
+    // The block owns ALL channels of its time tile (BM == C), so the 1x1 conv of the ResidualUnit runs here:
+    // h = snake_mid(acc + bias) goes to LDS once (channel-major tile, same layout as the epilogue tile) and is the
+    // B operand of a second MFMA pass whose A operand (the C x C weights, L1/L2 resident) streams straight into
+    // registers.  The intermediate activation never touches HBM and the skip input is re-read L2-hot.
+    const float* ep_bias = a.bias;
+    if (FUSE) {
+        float* const Ht = smem;                      // [BM][BNP]
+        __syncthreads();                              // staging buffers are free
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float bv = a.bias ? a.bias[row] : 0.0f;
+                const float al = a.alpha_mid[row], inv = 1.0f / (al + 1e-9f);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    Ht[row * C::BNP + (wn * NT + j) * 32 + l31] = det_snake(acc[i][j][r] + bv, al, inv);
+                    acc[i][j][r] = 0.0f;
+                }
+            }
+        __syncthreads();
+        constexpr int K2 = C::BM / 2;                 // k-steps of the 1x1 conv (K = C = BM)
+        constexpr int G = 8;                          // k-steps per register group of A operands
+        static_assert(K2 % G == 0, "BM must be a multiple of 16");
+        const float* w2 = a.w2p + (size_t)h * a.Mpad + wm * (MT * 32) + l31;
+        const float* hsrc = Ht + h * C::BNP + wn * (NT * 32) + l31;
+        float aw[2][G][MT];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) aw[0][g][i] = w2[(size_t)(2 * g) * a.Mpad + i * 32];
+#pragma unroll
+        for (int grp = 0; grp < K2 / G; ++grp) {
+            if (grp + 1 < K2 / G) {
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        aw[(grp + 1) & 1][g][i] = w2[(size_t)(2 * ((grp + 1) * G + g)) * a.Mpad + i * 32];
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int s2 = grp * G + g;
+                float bvv[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bvv[j] = hsrc[2 * s2 * C::BNP + j * 32];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[grp & 1][g][i], bvv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        ep_bias = a.bias2;
+    }
 
     // ---------------------------------------------------------------- epilogue
     // The accumulators go through LDS once (the staging buffers are free now) so that bias / residual / Snake /
@@ -299,7 +378,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 const bool mok = m < a.Mrows;
                 const int mc = mok ? m : a.Mrows - 1;
                 const int co = mc / a.up_s, rr = mc - co * a.up_s;
-                const float bv = a.bias ? a.bias[co] : 0.0f;
+                const float bv = ep_bias ? ep_bias[co] : 0.0f;
                 float al = 1.0f, inv = 1.0f;
                 if (snake_out) { al = a.alpha_out[co]; inv = 1.0f / (al + 1e-9f); }
                 const size_t rowoff = ((size_t)b * a.Cout + co) * a.Tout;
@@ -339,7 +418,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 const int c4 = e - row * (C::BN / 4);
                 const int m = m0 + row, n = n0 + 4 * c4;
                 if (m < a.Mrows && n < a.Ncols) {
-                    const float bv = a.bias ? a.bias[m] : 0.0f;
+                    const float bv = ep_bias ? ep_bias[m] : 0.0f;
                     f32x4 v = *reinterpret_cast<const f32x4*>(Ct + row * C::BNP + 4 * c4);
                     const size_t off = ((size_t)b * a.Cout + m) * a.Tout + n;
                     v.x = v.x + bv; v.y = v.y + bv; v.z = v.z + bv; v.w = v.w + bv;
@@ -365,7 +444,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 const int m = m0 + row, n = n0 + col;
                 if (m < a.Mrows && n < a.Ncols) {
                     const size_t off = ((size_t)b * a.Cout + m) * a.Tout + n;
-                    float v = Ct[row * C::BNP + col] + (a.bias ? a.bias[m] : 0.0f);
+                    float v = Ct[row * C::BNP + col] + (ep_bias ? ep_bias[m] : 0.0f);
                     if (has_res) v = v + a.residual[off];
                     if (snake_out) { const float al = a.alpha_out[m]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
                     if (do_tanh) v = det_tanh(v);
@@ -387,7 +466,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             const int co = m0 / S + col;
             const int t = t_base + tl;
             if (co < a.Cout && n0 + nl < a.Ncols && t >= 0 && t < a.Tout) {
-                float v = Ct[(col * S + rr) * C::BNP + nl] + (a.bias ? a.bias[co] : 0.0f);
+                float v = Ct[(col * S + rr) * C::BNP + nl] + (ep_bias ? ep_bias[co] : 0.0f);
                 if (snake_out) { const float al = a.alpha_out[co]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
                 a.y[((size_t)b * a.Cout + co) * a.Tout + t] = v;
             }
@@ -400,8 +479,40 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
 template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a)
 {
-    if (a.vec4) conv1d_mfma_body<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE, true>(a);
-    else conv1d_mfma_body<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE, false>(a);
+    if (a.vec4) conv1d_mfma_body<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE, true, false>(a);
+    else conv1d_mfma_body<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE, false, false>(a);
+}
+
+// whole ResidualUnit (7-tap dilated conv + Snake + 1x1 conv + skip) for C == BM
+template <int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void residual_unit_kernel(const ConvArgs a)
+{
+    if (a.vec4) conv1d_mfma_body<7, 1, DIL, CK, MT, NT, WAVES_M, WAVES_N, false, true, true>(a);
+    else conv1d_mfma_body<7, 1, DIL, CK, MT, NT, WAVES_M, WAVES_N, false, false, true>(a);
+}
+
+template <int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N>
+inline hipError_t launch_residual_unit(const ConvArgs& a_in, hipStream_t stream)
+{
+    using C = ConvCfg<7, 1, DIL, CK, MT, NT, WAVES_M, WAVES_N, false>;
+    ConvArgs a = a_in;
+    if (a.Cin % CK != 0 || a.Cout != C::BM || a.Cin != C::BM || a.Mpad != C::BM) return hipErrorInvalidValue;
+    a.n_tiles = (a.Ncols + C::BN - 1) / C::BN;
+    a.vec4 = (a.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+    a.ovec4 = (a.Tout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
+              ((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0);
+    const size_t lds = (size_t)C::LDS_FLOATS * 4 + (size_t)2 * a.Cin * 4;
+    auto kern = residual_unit_kernel<DIL, CK, MT, NT, WAVES_M, WAVES_N>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.n_tiles * a.B), 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    return hipGetLastError();
 }
 
 template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE>

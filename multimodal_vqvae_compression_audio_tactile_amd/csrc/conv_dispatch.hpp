@@ -8,4 +8,5 @@ hipError_t launch_conv_k7(const ConvArgs& a, int dil, int bm, hipStream_t s);   
 hipError_t launch_conv_k1k3(const ConvArgs& a, int ks, int bm, hipStream_t s);     // ks 1 or 3, stride 1
 hipError_t launch_conv_strided(const ConvArgs& a, int stride, int bm, hipStream_t s); // ks = 2*stride, stride 2/4/5/8
 hipError_t launch_conv_tr(const ConvArgs& a, int bm, hipStream_t s);               // polyphase ConvTranspose1d
+hipError_t launch_residual_unit_fused(const ConvArgs& a, int dil, hipStream_t s);   // C in {64, 96, 128}, dil 1/3/9
 }  // namespace mvq

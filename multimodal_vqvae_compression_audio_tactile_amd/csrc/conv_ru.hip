@@ -1,0 +1,24 @@
+// conv_ru.hip -- whole ResidualUnit in one launch for the narrow ends of the stacks (C = 64, 96, 128), where the
+// block tile covers every channel: conv7(dil) -> Snake -> conv1 -> + skip without the intermediate leaving the CU.
+#include "conv_dispatch.hpp"
+namespace mvq {
+template <int DIL>
+static hipError_t ru(const ConvArgs& a, int c, hipStream_t s)
+{
+    switch (c) {
+        case 128: return launch_residual_unit<DIL, 8, 2, 2, 2, 2>(a, s);
+        case 96:  return launch_residual_unit<DIL, 8, 3, 1, 1, 4>(a, s);
+        case 64:  return launch_residual_unit<DIL, 8, 2, 2, 1, 4>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t launch_residual_unit_fused(const ConvArgs& a, int dil, hipStream_t s)
+{
+    switch (dil) {
+        case 1: return ru<1>(a, a.Cout, s);
+        case 3: return ru<3>(a, a.Cout, s);
+        case 9: return ru<9>(a, a.Cout, s);
+    }
+    return hipErrorInvalidValue;
+}
+}  // namespace mvq

@@ -113,8 +113,9 @@ class WNConvTranspose1d(nn.Module):
 
 
 class ResidualUnit(nn.Module):
-    """x + conv1(snake(conv7_dilated(snake(x))))  -- two launches: the first applies Snake on load and the
-    second Snake on store, the second adds the skip (and optionally the NEXT layer's Snake) in its epilogue."""
+    """x + conv1(snake(conv7_dilated(snake(x)))) through mvq_residual_unit_f32: one fused launch for C <= 128,
+    otherwise two launches (Snake on load / on store in the first, skip add + the NEXT layer's Snake in the
+    epilogue of the second)."""
 
     def __init__(self, dim: int, dilation: int):
         super().__init__()
@@ -123,8 +124,9 @@ class ResidualUnit(nn.Module):
                                    Snake1d(dim), WNConv1d(dim, dim, 1))
 
     def run(self, x, alpha_next=None):
-        h = self.block[1].run(x, alpha_in=self.block[0].flat(), alpha_out=self.block[2].flat())
-        return self.block[3].run(h, residual=x, alpha_out=alpha_next)
+        c7, c1 = self.block[1], self.block[3]
+        return ops.residual_unit(x, c7.packed(), c7.bias.detach(), self.block[0].flat(), self.block[2].flat(),
+                                 c1.packed(), c1.bias.detach(), c7.dilation, alpha_next=alpha_next)
 
     def forward(self, x):
         return self.run(x)

@@ -94,6 +94,34 @@ def conv1d(x, wp, cout, ks, bias=None, stride=1, dil=1, pad=0, alpha_in=None, re
     return out
 
 
+def residual_unit_kernel_name(c, dil) -> str:
+    import ctypes
+    buf = ctypes.create_string_buffer(160)
+    check(_lib.lib().mvq_residual_unit_kernel_name(c, dil, buf, 160), "mvq_residual_unit_kernel_name")
+    return buf.value.decode()
+
+
+def residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None):
+    """The single-launch form (C in {64, 96, 128})."""
+    B, C, T = x.shape
+    y = torch.empty_like(x)
+    check(_lib.lib().mvq_residual_unit_f32(x.data_ptr(), w7p.data_ptr(), _p(b7), alpha_a.data_ptr(), alpha_b.data_ptr(),
+                                           w1p.data_ptr(), _p(b1), _p(alpha_next), y.data_ptr(), None,
+                                           B, C, T, dil, _stream()), "mvq_residual_unit_f32")
+    return y
+
+
+def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None):
+    """x + conv1(snake(conv7_dil(snake(x)))) (+ the next Snake1d): one fused launch for C in {64,96,128}, else the
+    two conv launches (Snake on load / on store in the first, skip + next Snake in the second's epilogue)."""
+    x = _dev(x, "x")
+    B, C, T = x.shape
+    if _lib.lib().mvq_residual_unit_scratch_floats(B, C, T, dil) == 0:
+        return residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next)
+    h = conv1d(x, w7p, C, 7, bias=b7, dil=dil, pad=3 * dil, alpha_in=alpha_a, alpha_out=alpha_b)
+    return conv1d(h, w1p, C, 1, bias=b1, residual=x, alpha_out=alpha_next)
+
+
 def conv_transpose1d(x, wp, cout, stride, pad, bias=None, alpha_in=None, alpha_out=None):
     x = _dev(x, "x")
     B, cin, tin = x.shape

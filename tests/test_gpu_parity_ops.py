@@ -198,3 +198,28 @@ def test_ops_refuse_cpu_tensors():
     from multimodal_vqvae_compression_audio_tactile_amd._lib import MvqError
     with pytest.raises(MvqError):
         ops.gelu(torch.zeros(4))
+
+
+RU_CASES = [(2, 64, 1000, 1, True), (1, 64, 517, 9, False), (2, 96, 700, 3, True), (1, 96, 333, 1, False),
+            (2, 128, 600, 9, True), (1, 128, 257, 3, False), (1, 192, 300, 3, True), (1, 256, 75, 1, False)]
+
+
+@pytest.mark.parametrize("case", RU_CASES, ids=[f"ru{i}" for i in range(len(RU_CASES))])
+def test_residual_unit_bit_exact(case, orc, dev):
+    """mvq_residual_unit_f32 (fused for C in {64,96,128}, two launches otherwise) == the two oracle convs."""
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    B, C, T, dil, nxt = case
+    r = _rng(C * 7 + T + dil)
+    x = r.standard_normal((B, C, T)).astype(np.float32)
+    w7 = (r.standard_normal((C, C, 7)) / math.sqrt(C * 7)).astype(np.float32)
+    w1 = (r.standard_normal((C, C, 1)) / math.sqrt(C)).astype(np.float32)
+    b7 = (0.1 * r.standard_normal(C)).astype(np.float32); b1 = (0.1 * r.standard_normal(C)).astype(np.float32)
+    aa = r.uniform(0.5, 1.5, C).astype(np.float32); ab = r.uniform(0.5, 1.5, C).astype(np.float32)
+    an = r.uniform(0.5, 1.5, C).astype(np.float32) if nxt else None
+    h = orc.conv1d(x, w7, b7, dil=dil, pad=3 * dil, alpha_in=aa)
+    want = orc.conv1d(h, w1, b1, alpha_in=ab, residual=x, alpha_out=an)
+    got = ops.residual_unit(_t(x, dev), ops.pack_conv1d(_t(w7, dev)), _t(b7, dev), _t(aa, dev), _t(ab, dev),
+                            ops.pack_conv1d(_t(w1, dev)), _t(b1, dev), dil,
+                            alpha_next=None if an is None else _t(an, dev))
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want), f"max abs diff {np.abs(got.cpu().numpy() - want).max()}"

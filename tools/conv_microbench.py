@@ -11,6 +11,10 @@ flt = sys.argv[2] if len(sys.argv) > 2 else ""
 dev = torch.device("cuda:0")
 layers = []   # (name, kind, Cin, Cout, ks, stride, dil, Tin, alpha_in, residual, alpha_out, count)
 def ru(prefix, C, T, n):
+    if C <= 128:
+        for d in (1, 3, 9):
+            layers.append((f"{prefix}.RUd{d}", "r", C, C, 7, 1, d, T, True, True, False, n))
+        return
     for d in (1, 3, 9):
         layers.append((f"{prefix}.k7d{d}", "c", C, C, 7, 1, d, T, True, False, True, n))
     layers.append((f"{prefix}.k1", "c", C, C, 1, 1, 1, T, False, True, False, 3 * n))
@@ -41,7 +45,15 @@ for (name, kind, cin, cout, ks, st, dil, tin, ai, res, ao, count) in layers:
     else:
         x = torch.randn(B, cin, tin, device=dev)
     Bx, _, Tx = x.shape
-    if kind == "t":
+    if kind == "r":
+        w7 = ops.pack_conv1d(torch.randn(cout, cin, 7, device=dev) / math.sqrt(cin * 7))
+        w1 = ops.pack_conv1d(torch.randn(cout, cin, 1, device=dev) / math.sqrt(cin))
+        b7 = torch.randn(cout, device=dev); b1 = torch.randn(cout, device=dev)
+        aa = torch.rand(cin, device=dev) + 0.5; ab = torch.rand(cin, device=dev) + 0.5
+        f = lambda: ops.residual_unit(x, w7, b7, aa, ab, w1, b1, dil)
+        flops = 2.0 * cin * cout * 8 * Tx * Bx
+        kname = "       residual_unit_kernel"
+    elif kind == "t":
         w = torch.randn(cin, cout, ks, device=dev) / math.sqrt(cin * 2)
         wp = ops.pack_conv_transpose1d(w, st)
         f = lambda: ops.conv_transpose1d(x, wp, cout, st, math.ceil(st / 2))
