@@ -1,0 +1,56 @@
+"""Multi-GPU use of the path: one process per GPU, ``torch.distributed`` ("nccl" == RCCL over xGMI on ROCm).
+
+Segments are independent (the AR dependency is inside a segment), so inference shards them across ranks with NO
+data-path collective.  The only exchange the algorithm has is the codebook EMA update of the
+training config (``ResidualVQEMA.ema_step``, Training/compare_dacvsproposal_5.py:266-277, called at ...:396-397):
+every rank must apply the SAME update.  ``ema_step_all_ranks`` all-gathers the detached ``r_tokens`` (B*75*96 fp32
+per rank: ~170 KB at the reference batch of 6 -- latency-bound on xGMI, one collective) in rank order and then runs
+the identical deterministic ``ema_step`` on every rank, which preserves the reference's token-order sums bit for bit
+(an all-reduce of partial sums would change the summation order).
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [start, end) slice of n_items for `rank` (sizes differ by at most one)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_round_robin(n_items: int, rank: int, world: int) -> List[int]:
+    """Segment i -> rank i mod world (the corpus config of SURVEY.md section 8d)."""
+    return list(range(rank, n_items, world))
+
+
+def gather_tokens(r_tokens: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather [B,D,T] token tensors along the batch axis in rank order (every rank gets the same tensor).
+    Per-rank batch sizes may differ (uneven shards): sizes are exchanged first."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return r_tokens
+    world = dist.get_world_size(group)
+    r_tokens = r_tokens.contiguous()
+    nb = torch.tensor([r_tokens.shape[0]], device=r_tokens.device, dtype=torch.int64)
+    sizes = [torch.zeros_like(nb) for _ in range(world)]
+    dist.all_gather(sizes, nb, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    bmax = max(sizes)
+    pad = r_tokens
+    if r_tokens.shape[0] < bmax:
+        pad = torch.zeros((bmax,) + tuple(r_tokens.shape[1:]), device=r_tokens.device, dtype=r_tokens.dtype)
+        pad[: r_tokens.shape[0]] = r_tokens
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
+
+
+def ema_step_all_ranks(vq, r_tokens: torch.Tensor, group=None) -> None:
+    """Distributed form of `net.vq.ema_step(out["r_tokens"])`: identical codebooks on every rank afterwards."""
+    vq.ema_step(gather_tokens(r_tokens, group))

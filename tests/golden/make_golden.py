@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own classes (run in the build container only).
+
+  python tests/golden/make_golden.py
+
+Imports /root/reference through oracle/ref_import.py (stand-ins for dac / torchaudio / soundfile, os.makedirs
+patched) and records inputs-by-seed + expected outputs of:
+  G1 ResidualVQEMA.forward            (Training/compare_dacvsproposal_5.py:246-265 and the eval variant with
+                                        n_books_use, Evaluation/dac_vcpwq_proposed6_latency.py:409-435)
+  G2 ResidualVQEMA.ema_step           (Training/compare_dacvsproposal_5.py:266-277)
+  G3 CrossPredictor.forward           (Training/compare_dacvsproposal_5.py:226-244), eval mode
+  G4 ProposedEval.encode_latents / forward_eval (Evaluation/dac_vcpwq_proposed6_latency.py:451-487) driven with the
+     torch restatement of the DAC backbones as A_ENC / A_QUANT / T_ENC / T_DEC (the real `dac` package is absent)
+  G5 psnr_batch / psnr_global_peak_db (Evaluation/compare_dacvsproposal_5_eval.py:180-185, ...6_latency.py:204-214)
+Only data is stored (arrays), never reference source.  Inputs are re-created from seeds by tests/golden_inputs.py.
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import golden_inputs as gi                      # noqa: E402
+from oracle import dac24_torch as T             # noqa: E402
+from oracle import ref_import                   # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+torch.set_grad_enabled(False)
+torch.manual_seed(0)
+
+
+def main():
+    assert ref_import.available(), "reference not mounted"
+    tr, ev, e5 = ref_import.training(), ref_import.evaluation(), ref_import.eval5()
+
+    # ---- G1: RVQ forward
+    g1 = {}
+    for name, (K, nb, use, B, Tt, seed) in gi.RVQ_CASES.items():
+        z, books = gi.rvq_inputs(K, nb, B, Tt, seed)
+        m = ev.ResidualVQEMA(dim=96, n_books=nb, n_embed=K)
+        for p, b in zip(m.books, books):
+            p.data.copy_(torch.from_numpy(b))
+        q_eval = m(torch.from_numpy(z), n_books_use=use).numpy()
+        mt = tr.ResidualVQEMA(dim=96, n_books=nb, n_embed=K, decay=0.99)
+        for p, b in zip(mt.books, books):
+            p.data.copy_(torch.from_numpy(b))
+        # per-book indices exactly as the reference computes them
+        x = torch.from_numpy(z).permute(0, 2, 1).reshape(-1, 96)
+        res, idxs = x, []
+        for cb in list(mt.books)[:(nb if use is None else min(use, nb))]:
+            i = mt._nearest_l2(res, cb.detach())
+            idxs.append(i.numpy().astype(np.int16))
+            res = res - torch.nn.functional.embedding(i, cb.detach())
+        g1[f"{name}.q"] = q_eval
+        g1[f"{name}.idx"] = np.stack(idxs)
+        if use is None:
+            g1[f"{name}.q_train"] = mt(torch.from_numpy(z)).numpy()
+    np.savez_compressed(OUT / "g1_rvq_forward.npz", **g1)
+
+    # ---- G2: EMA step
+    g2 = {}
+    for name, (K, nb, B, Tt, seed) in gi.EMA_CASES.items():
+        z, books = gi.rvq_inputs(K, nb, B, Tt, seed)
+        m = tr.ResidualVQEMA(dim=96, n_books=nb, n_embed=K, decay=0.99)
+        for p, b in zip(m.books, books):
+            p.data.copy_(torch.from_numpy(b))
+        m.ema_step(torch.from_numpy(z))
+        g2[f"{name}.books_after"] = np.stack([p.detach().numpy() for p in m.books])
+    np.savez_compressed(OUT / "g2_ema_step.npz", **g2)
+
+    # ---- G3: CrossPredictor
+    g3 = {}
+    sd = gi.head_state()
+    cp = tr.CrossPredictor(c=1024, heads=8, mlp_mul=2, dropout=0.1).eval()
+    cp.load_state_dict({k[len("predict."):]: v for k, v in sd.items() if k.startswith("predict.")}, strict=True)
+    for name, (B, Tq, Tk, seed) in gi.CP_CASES.items():
+        zt_prev, za = gi.cp_inputs(B, Tq, Tk, seed)
+        g3[name] = cp(torch.from_numpy(zt_prev), torch.from_numpy(za)).numpy()
+    np.savez_compressed(OUT / "g3_cross_predictor.npz", **g3)
+
+    # ---- G4: ProposedEval with restated backbones
+    g4 = {}
+    for name, (books, K, use, B, seed) in gi.PE_CASES.items():
+        sdm = gi.model_state(seed, books, K)
+        a, t = gi.pe_inputs(B, seed)
+        da, dt = T.DAC(), T.DAC()
+        net = ev.ProposedEval(da.encoder, da.quantizer, dt.encoder, dt.decoder, c_lat=1024, rvq_books=books, rvq_embed=K)
+        net.load_state_dict(sdm, strict=True)
+        net.eval()
+        z_run = net.encode_latents(a, t, books_use=use)
+        y = net.forward_eval(a, t, books_use=use)
+        Tm = y.shape[-1]
+        g4[f"{name}.z_run"] = z_run.numpy()
+        g4[f"{name}.y"] = y.numpy()
+        g4[f"{name}.psnr"] = np.array(e5.psnr_batch(t[..., :Tm], y), np.float64)
+    np.savez_compressed(OUT / "g4_proposed_eval.npz", **g4)
+
+    # ---- G5: PSNR helpers
+    r = np.random.default_rng(5)
+    ref = r.uniform(-1, 1, (3, 1, 4000)).astype(np.float32)
+    est = (ref + 0.01 * r.standard_normal(ref.shape)).astype(np.float32)
+    g5 = {"ref": ref, "est": est,
+          "psnr_batch": np.array(e5.psnr_batch(torch.from_numpy(ref), torch.from_numpy(est)), np.float64),
+          "psnr_global": np.array([ev.psnr_global_peak_db(torch.from_numpy(ref[i]), torch.from_numpy(est[i]), 4.3857)
+                                   for i in range(3)], np.float64)}
+    np.savez_compressed(OUT / "g5_psnr.npz", **g5)
+    for f in sorted(OUT.glob("*.npz")):
+        print(f.name, f.stat().st_size // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

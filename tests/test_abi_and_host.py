@@ -1,0 +1,80 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mvq.h declares; host-side logic that needs no GPU
+(shape helpers, packed sizes, state-dict compatibility of the module mirror, loud failure without a device)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared():
+    txt = (ROOT / "include" / "mvq.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mvq_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from multimodal_vqvae_compression_audio_tactile_amd import _lib
+    names = _declared()
+    assert len(names) >= 20
+    so = ctypes.CDLL(str(_lib.SO_PATH))
+    missing = [n for n in names if not hasattr(so, n)]
+    assert not missing, missing
+    assert sorted(_lib.EXPORTS) == names, set(names) ^ set(_lib.EXPORTS)     # the ctypes table binds all of them
+    assert _lib.lib().mvq_abi_version() == 1
+
+
+def test_host_only_entry_points():
+    from multimodal_vqvae_compression_audio_tactile_amd import _lib, ops
+    lib = _lib.lib()
+    assert lib.mvq_conv1d_packed_floats(768, 768, 7) == 768 * 7 * 768
+    assert lib.mvq_conv1d_packed_floats(96, 96, 1) == 96 * 96              # BM=96 tile: no padding
+    assert lib.mvq_conv1d_packed_floats(1, 64, 7) == 7 * 64
+    assert lib.mvq_conv1d_packed_floats(1024, 8, 1) == 1024 * 64           # tiny Cout padded to one 64-row tile
+    assert lib.mvq_conv_transpose1d_packed_floats(1536, 768, 8) == 1536 * 2 * 768 * 8
+    assert lib.mvq_residual_unit_scratch_floats(4, 96, 1000, 3) == 0       # fused
+    assert lib.mvq_residual_unit_scratch_floats(4, 768, 600, 9) == 4 * 768 * 600
+    assert ops.conv_kernel_name(768, 768, 7, 1, 9).startswith("conv1d_mfma_kernel<7, 1, 9")
+    assert ops.conv_kernel_name(1, 64, 7) == "conv1d_direct_kernel"
+    assert ops.conv1d_out_len(24000, 4, 2, 1, 1) == 12000 and ops.conv1d_out_len(600, 16, 8, 1, 4) == 75
+    assert ops.conv1d_out_len(3, 7, 1, 9, 0) == 0
+    assert lib.mvq_conv1d_f32(None, None, None, None, None, None, None, 1, -3, 5, 4, 7, 1, 1, 3, 0, None) == -1
+    assert b"bad shape" in lib.mvq_last_error()
+
+
+def test_module_mirror_loads_reference_shaped_state_dicts():
+    import multimodal_vqvae_compression_audio_tactile_amd as mvq
+    from multimodal_vqvae_compression_audio_tactile_amd import synth
+    from oracle import dac24_torch as T
+    sd = synth.proposed_model_state(3, rvq_books=3, rvq_embed=128)
+    da, dt = mvq.DAC(), mvq.DAC()
+    net = mvq.ProposedEval(da.encoder, da.quantizer, dt.encoder, dt.decoder, 1024, 3, 128)
+    assert not any(p.requires_grad for m in (net.A_ENC, net.A_QUANT, net.T_ENC, net.T_DEC) for p in m.parameters())
+    res = net.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    # identical key set / shapes as the torch restatement (== upstream parameter names)
+    ref = T.ProposedEval(rvq_books=3, rvq_embed=128)
+    a = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert a == b
+    # get_n_books_and_bins probe of the reference (compare_dacvsproposal_5_eval.py:233-246)
+    assert net.A_QUANT.n_q == 32 and net.A_QUANT.bins == 1024
+    assert sum(p.numel() for p in da.encoder.parameters()) == 21521536
+    dac_sd = synth.dac_state(5, n_codebooks=4)
+    mvq.DAC(n_codebooks=4).load_state_dict(dac_sd, strict=True)
+
+
+def test_no_cpu_fallback():
+    import multimodal_vqvae_compression_audio_tactile_amd as mvq
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    with pytest.raises(mvq.MvqError):
+        ops.conv1d(torch.zeros(1, 64, 100), torch.zeros(64 * 7 * 64), 64, 7, pad=3)
+    enc = mvq.Encoder()
+    with pytest.raises(mvq.MvqError):
+        enc(torch.zeros(1, 1, 3200))
+    vq = mvq.ResidualVQEMA(96, 2, 128)
+    with pytest.raises(mvq.MvqError):
+        vq(torch.zeros(1, 96, 16))

@@ -1,0 +1,70 @@
+"""CPU, world_size 2 over gloo: the N>1 plumbing (segment sharding, rank-ordered token all-gather for the EMA update).
+The EMA arithmetic itself is the oracle's here (the product kernels need a GPU); what is under test is that every
+rank ends with identical codebooks equal to the single-process result on the concatenated batch."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from multimodal_vqvae_compression_audio_tactile_amd import dist as mdist
+    from oracle import oracle as orc
+    import golden_inputs as gi
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z, books = gi.rvq_inputs(128, 3, 7, 75, 4242)             # 7 segments: uneven shards (4 + 3)
+    s, e = mdist.shard_range(z.shape[0], rank, world)
+    local = torch.from_numpy(z[s:e])
+
+    class OracleVQ:                                           # stands in for ResidualVQEMA on a GPU-less host
+        def __init__(self): self.books = np.stack(books)
+        def ema_step(self, tokens): self.books, _ = orc.rvq_ema_step(tokens.numpy(), list(self.books), 0.99)
+
+    vq = OracleVQ()
+    mdist.ema_step_all_ranks(vq, local)
+    np.save(os.path.join(out_dir, f"books_{rank}.npy"), vq.books)
+    gathered = mdist.gather_tokens(local)
+    np.save(os.path.join(out_dir, f"tok_{rank}.npy"), gathered.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ema_update_identical_on_all_ranks(tmp_path, orc):
+    import golden_inputs as gi
+    world = 2
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    z, books = gi.rvq_inputs(128, 3, 7, 75, 4242)
+    want, _ = orc.rvq_ema_step(z, books, 0.99)
+    b0, b1 = np.load(tmp_path / "books_0.npy"), np.load(tmp_path / "books_1.npy")
+    assert np.array_equal(b0, b1)
+    assert np.array_equal(b0, want)                           # == single process on the whole batch, bit for bit
+    assert np.array_equal(np.load(tmp_path / "tok_0.npy"), z) and np.array_equal(np.load(tmp_path / "tok_1.npy"), z)
+
+
+def test_sharding_covers_every_segment_once():
+    from multimodal_vqvae_compression_audio_tactile_amd import dist as mdist
+    for n in (0, 1, 7, 8, 1003):
+        for world in (1, 2, 4, 8):
+            seen = []
+            for r in range(world):
+                s, e = mdist.shard_range(n, r, world)
+                seen += list(range(s, e))
+            assert seen == list(range(n))
+            rr = sorted(i for r in range(world) for i in mdist.shard_round_robin(n, r, world))
+            assert rr == list(range(n))
+    with pytest.raises(ValueError):
+        mdist.shard_range(4, 2, 2)
