@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="1-s segments per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="1-s segments per GPU per step")
     ap.add_argument("--workload", choices=["joint", "tactile"], default="joint")
     ap.add_argument("--books", type=int, default=8)
     ap.add_argument("--embed", type=int, default=512)
@@ -75,7 +75,7 @@ class KernelEvents:
             e0.record()
             y = orig_conv(x, wp, cout, ks, bias=bias, stride=stride, dil=dil, pad=pad, **kw)
             e1.record()
-            rec.append((ops.conv_kernel_name(cin, cout, ks, stride, dil), 2.0 * cin * cout * ks * tout * B, e0, e1))
+            rec.append((ops.conv_kernel_name(cin, cout, ks, stride, dil, tin=tin), 2.0 * cin * cout * ks * tout * B, e0, e1))
             return y
 
         def conv_transpose1d(x, wp, cout, stride, pad, **kw):
@@ -84,7 +84,7 @@ class KernelEvents:
             e0.record()
             y = orig_tr(x, wp, cout, stride, pad, **kw)
             e1.record()
-            rec.append((ops.conv_kernel_name(cin, cout, 2 * stride, stride, 1, transposed=True),
+            rec.append((ops.conv_kernel_name(cin, cout, 2 * stride, stride, 1, transposed=True, tin=tin),
                         2.0 * cin * cout * 2 * stride * tin * B, e0, e1))
             return y
 

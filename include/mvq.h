@@ -73,8 +73,9 @@ int mvq_conv1d_f32(const float* x, const float* wp, const float* bias, const flo
 
 /* Name of the kernel instantiation the two conv entry points launch for a shape ("conv1d_mfma_kernel<...>" as
  * rocprofv3 prints it, or "conv1d_direct_kernel"): lets bench.py match its HIP-event timings to the trace.
- * For transposed convs pass the torch shape (cin, cout, ks = 2*stride, stride). */
-int mvq_conv_kernel_name(int cin, int cout, int ks, int stride, int dil, int transposed, char* buf, int len);
+ * For transposed convs pass the torch shape (cin, cout, ks = 2*stride, stride).  tin = input length (tile shape
+ * depends on it for the latent-rate layers; "same"/DAC padding is assumed). */
+int mvq_conv_kernel_name(int cin, int cout, int ks, int stride, int dil, int transposed, int tin, char* buf, int len);
 
 /* One upstream dac ResidualUnit:  y = snake_next?( x + conv1( snake_b( conv7_dil( snake_a(x) ) + b7 ) ) + b1 ),
  * 7-tap conv with dilation `dil` and padding 3*dil, then a 1x1 conv, both C -> C.  For C in {64, 96, 128} (the
@@ -135,7 +136,7 @@ int mvq_layernorm_c_f32(const float* x, const float* pe, const float* gamma, con
 
 /* softmax(Q K^T / sqrt(dh)) V per head (Training/compare_dacvsproposal_5.py:239-242).  Q, ctx: (b,c,i) at
  * b*q_stride_b + c*q_stride_c + i ; K, V: (b,c,j) at b*k_stride_b + c*k_stride_c + j (0,0 = contiguous).
- * Tk may be 0 (ctx = 0).  Tk <= 64. */
+ * Tk may be 0 (ctx = 0).  Tq, Tk <= 64 and dh*(Tq+2Tk)+Tq*Tk <= 16384 floats (one head slice lives in LDS). */
 int mvq_attention_f32(const float* q, const float* k, const float* v, float* ctx,
                       int batch, int heads, int dh, int tq, int tk,
                       size_t q_stride_b, size_t q_stride_c, size_t k_stride_b, size_t k_stride_c, void* stream);

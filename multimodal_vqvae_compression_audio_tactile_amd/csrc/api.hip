@@ -80,15 +80,18 @@ int mvq_conv_transpose1d_pack_f32(const float* w, float* wp, int cin, int cout, 
 }
 
 /* which kernel instantiation mvq_conv1d_f32 / mvq_conv_transpose1d_f32 launches for a shape (profiling aid) */
-int mvq_conv_kernel_name(int cin, int cout, int ks, int stride, int dil, int transposed, char* buf, int len)
+int mvq_conv_kernel_name(int cin, int cout, int ks, int stride, int dil, int transposed, int tin, char* buf, int len)
 {
     if (!buf || len <= 0) return fail(MVQ_EINVAL, "conv_kernel_name: bad buffer");
     const int mrows = transposed ? cout * stride : cout;
     const int bm = mvq::conv_tile_bm(mrows);
-    const char* tile = bm == 128 ? "2, 2, 2, 2" : (bm == 96 ? "3, 1, 1, 4" : "2, 2, 1, 4");
+    const int ncols = transposed ? tin + 1 : conv_out_len(tin, ks, stride, dil, transposed ? 0 : (stride == 1 ? (ks - 1) * dil / 2 : (stride + 1) / 2));
+    const bool narrow = bm == 128 && ncols > 0 && ncols <= 96 &&
+                        (transposed || (ks == 7 && dil == 1 && stride == 1) || ks == 3 || (ks == 16 && stride == 8));
+    const char* tile = narrow ? "1, 3, 4, 1" : (bm == 128 ? "2, 2, 2, 2" : (bm == 96 ? "3, 1, 1, 4" : "2, 2, 1, 4"));
     int K = 0, S = 1, D = 1, CK = 0;
     if (transposed) {
-        if (cin % 32 == 0 && mrows >= 64) { K = 2; CK = 32; }
+        if (cin % 32 == 0 && ((bm == 128 && (stride == 8 || stride == 5 || stride == 4 || stride == 2)) || (bm == 96 && stride == 2))) { K = 2; CK = 32; }
     } else if (cout >= 32 && cin >= 32) {
         if (ks == 7 && stride == 1 && cin % 8 == 0 && (dil == 1 || dil == 3 || dil == 9)) { K = 7; D = dil; CK = 8; }
         else if (ks == 1 && stride == 1 && dil == 1 && cin % 32 == 0) { K = 1; CK = 32; }
@@ -98,7 +101,7 @@ int mvq_conv_kernel_name(int cin, int cout, int ks, int stride, int dil, int tra
         }
     }
     if (K == 0) snprintf(buf, len, "%s", transposed ? "convtr_direct_kernel" : "conv1d_direct_kernel");
-    else snprintf(buf, len, "conv1d_mfma_kernel<%d, %d, %d, %d, %s, %s>", K, S, D, CK, tile, transposed ? "true" : "false");
+    else snprintf(buf, len, "conv1d_mfma_kernel<%d, %d, %d, %d, %s, %d>", K, S, D, CK, tile, transposed ? stride : 0);
     return MVQ_OK;
 }
 
@@ -266,7 +269,8 @@ int mvq_attention_f32(const float* q, const float* k, const float* v, float* ctx
                       int batch, int heads, int dh, int tq, int tk,
                       size_t q_stride_b, size_t q_stride_c, size_t k_stride_b, size_t k_stride_c, void* stream)
 {
-    if (batch < 0 || heads <= 0 || dh <= 0 || tq < 0 || tk < 0 || tk > 64) return fail(MVQ_EINVAL, "attention: bad shape (Tk <= 64)");
+    if (batch < 0 || heads <= 0 || dh <= 0 || tq < 0 || tk < 0 || tk > 64 || tq > 64 || (size_t)dh * (tq + 2 * tk) + (size_t)tq * tk > 16384)
+        return fail(MVQ_EINVAL, "attention: bad shape (Tq, Tk <= 64; head slices must fit 64 KiB of LDS)");
     if (batch == 0 || tq == 0) return MVQ_OK;
     if (!q || !ctx || (tk > 0 && (!k || !v))) return fail(MVQ_EINVAL, "attention: null tensor");
     const size_t c = (size_t)heads * dh;

@@ -8,7 +8,7 @@
 // an exact k-ordered fp32 fma chain, so walking K as "ci ascending, tap ascending" reproduces the
 // arithmetic contract of include/mvq.h bit for bit.
 //
-// Block = 256 threads = 4 waves; wave tile = (32*MT) x (32*NT); block tile BM x BN.  K is walked in chunks
+// Block = 64*WAVES_M*WAVES_N threads (4 or 8 waves); wave tile = (32*MT) x (32*NT); block tile BM x BN.  K is walked in chunks
 // of CK input channels (CK*KS even).  Pipeline per chunk c (one barrier per chunk, two LDS buffers):
 //     issue the global loads of chunk c+1 into registers (raw, branch-free, 16-byte when rows are aligned)
 //     MFMA over chunk c out of LDS, operands for k-step s+1 fetched before the MFMAs of step s
@@ -37,11 +37,11 @@ struct ConvArgs {
     int B, Cin, Tin, Cout, Tout;
     int pad;                // left zero padding in input samples
     int Mpad;               // padded M (row pitch of wp)
-    int Mrows;              // valid GEMM rows (Cout, or Cout*S for SHUFFLE)
-    int Ncols;              // GEMM columns per batch element (Tout, or Tin+1 for SHUFFLE)
+    int Mrows;              // valid GEMM rows (Cout, or Cout*S for UPS)
+    int Ncols;              // GEMM columns per batch element (Tout, or Tin+1 for UPS)
     int n_tiles;            // ceil(Ncols / BN)
     int act;
-    int up_s, up_p;         // SHUFFLE: stride S and torch padding P
+    int up_s, up_p;         // UPS: stride S and torch padding P
     int vec4;               // input rows are 16-byte aligned (Tin % 4 == 0 and x 16-byte aligned)
     int ovec4;              // output (and residual) rows are 16-byte aligned (Tout % 4 == 0, pointers aligned)
     // fused ResidualUnit (FUSE kernels): y = x + conv1(snake_mid(conv7(snake_in(x)) + bias) ) + bias2, then alpha_out
@@ -50,7 +50,7 @@ struct ConvArgs {
     const float* bias2;     // [C] or null
 };
 
-template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE>
+template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, int UPS>
 struct ConvCfg {
     static constexpr int BM = 32 * MT * WAVES_M;
     static constexpr int BN = 32 * NT * WAVES_N;
@@ -65,22 +65,23 @@ struct ConvCfg {
     static constexpr int CT_FLOATS = BM * BNP;
     static constexpr int LDS_FLOATS = STAGE_FLOATS > CT_FLOATS ? STAGE_FLOATS : CT_FLOATS;
     static constexpr int W_VEC = W_FLOATS / 4;                           // float4 per chunk
-    static constexpr int W_PER_THREAD = (W_VEC + 255) / 256;
+    static constexpr int NTHR = 64 * WAVES_M * WAVES_N;                  // threads per block
+    static constexpr int W_PER_THREAD = (W_VEC + NTHR - 1) / NTHR;
     static constexpr int XV_TOTAL = CK * XV;
-    static constexpr int XV_PER_THREAD = (XV_TOTAL + 255) / 256;         // float4 path
+    static constexpr int XV_PER_THREAD = (XV_TOTAL + NTHR - 1) / NTHR;         // float4 path
     static constexpr int XS_TOTAL = CK * XT;
-    static constexpr int XS_PER_THREAD = (XS_TOTAL + 255) / 256;         // scalar path
+    static constexpr int XS_PER_THREAD = (XS_TOTAL + NTHR - 1) / NTHR;         // scalar path
     static constexpr int XREGS = (4 * XV_PER_THREAD > XS_PER_THREAD) ? 4 * XV_PER_THREAD : XS_PER_THREAD;
-    static_assert(WAVES_M * WAVES_N == 4, "block is 4 waves");
+    static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "block is 4 or 8 waves");
     static_assert(KC % 2 == 0, "chunk K must be even (32x32x2 MFMA)");
     static_assert(BM % 4 == 0, "float4 weight staging");
 };
 
 // Per-thread view of one block's staging / MFMA work.  Plain force-inlined member functions over register
 // arrays (lambdas capturing the arrays by reference kept them in scratch memory).
-template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE, bool VEC>
+template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, int UPS, bool VEC>
 struct ConvTile {
-    using C = ConvCfg<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE>;
+    using C = ConvCfg<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS>;
     const float* wp; const float* xb; const float* Al;
     float* Ws; float* Xs;
     int tid, Tin, Cin, Mpad, m0, t_in0, g_al;
@@ -93,8 +94,8 @@ struct ConvTile {
         const float* wsrc = wp + (size_t)ci0 * KS * Mpad + m0;
 #pragma unroll
         for (int u = 0; u < C::W_PER_THREAD; ++u) {
-            int v = tid + u * 256;
-            if (C::W_VEC % 256 != 0) v = v < C::W_VEC ? v : C::W_VEC - 1;
+            int v = tid + u * C::NTHR;
+            if (C::W_VEC % C::NTHR != 0) v = v < C::W_VEC ? v : C::W_VEC - 1;
             const int row = v / (C::BM / 4);
             const int c4 = v - row * (C::BM / 4);
             wreg[u] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)row * Mpad + c4 * 4);
@@ -102,8 +103,8 @@ struct ConvTile {
         if (VEC) {
 #pragma unroll
             for (int u = 0; u < C::XV_PER_THREAD; ++u) {
-                int e = tid + u * 256;
-                if (C::XV_TOTAL % 256 != 0) e = e < C::XV_TOTAL ? e : C::XV_TOTAL - 1;
+                int e = tid + u * C::NTHR;
+                if (C::XV_TOTAL % C::NTHR != 0) e = e < C::XV_TOTAL ? e : C::XV_TOTAL - 1;
                 const int cl = e / C::XV;
                 const int v = e - cl * C::XV;
                 const int g = g_al + 4 * v;                       // multiple of 4: fully inside or fully outside
@@ -114,8 +115,8 @@ struct ConvTile {
         } else {
 #pragma unroll
             for (int u = 0; u < C::XS_PER_THREAD; ++u) {
-                int e = tid + u * 256;
-                if (C::XS_TOTAL % 256 != 0) e = e < C::XS_TOTAL ? e : C::XS_TOTAL - 1;
+                int e = tid + u * C::NTHR;
+                if (C::XS_TOTAL % C::NTHR != 0) e = e < C::XS_TOTAL ? e : C::XS_TOTAL - 1;
                 const int cl = e / C::XT;
                 const int xi = e - cl * C::XT;
                 const int g = t_in0 + xi;
@@ -136,14 +137,14 @@ struct ConvTile {
         float* xdst = Xs + buf * C::X_FLOATS;
 #pragma unroll
         for (int u = 0; u < C::W_PER_THREAD; ++u) {
-            const int v = tid + u * 256;
-            if (C::W_VEC % 256 == 0 || v < C::W_VEC) *reinterpret_cast<f32x4*>(wdst + v * 4) = wreg[u];
+            const int v = tid + u * C::NTHR;
+            if (C::W_VEC % C::NTHR == 0 || v < C::W_VEC) *reinterpret_cast<f32x4*>(wdst + v * 4) = wreg[u];
         }
         if (VEC) {
 #pragma unroll
             for (int u = 0; u < C::XV_PER_THREAD; ++u) {
-                const int e = tid + u * 256;
-                const int ec = (C::XV_TOTAL % 256 != 0 && e >= C::XV_TOTAL) ? C::XV_TOTAL - 1 : e;
+                const int e = tid + u * C::NTHR;
+                const int ec = (C::XV_TOTAL % C::NTHR != 0 && e >= C::XV_TOTAL) ? C::XV_TOTAL - 1 : e;
                 const int cl = ec / C::XV;
                 const int v = ec - cl * C::XV;
                 const int g = g_al + 4 * v;
@@ -155,29 +156,29 @@ struct ConvTile {
                     q.x = det_snake(q.x, al, inv); q.y = det_snake(q.y, al, inv);
                     q.z = det_snake(q.z, al, inv); q.w = det_snake(q.w, al, inv);
                 }
-                if (C::XV_TOTAL % 256 == 0 || e < C::XV_TOTAL)
+                if (C::XV_TOTAL % C::NTHR == 0 || e < C::XV_TOTAL)
                     *reinterpret_cast<f32x4*>(xdst + cl * C::XTP + 4 * v) = q;
             }
         } else {
 #pragma unroll
             for (int u = 0; u < C::XS_PER_THREAD; ++u) {
-                const int e = tid + u * 256;
-                const int ec = (C::XS_TOTAL % 256 != 0 && e >= C::XS_TOTAL) ? C::XS_TOTAL - 1 : e;
+                const int e = tid + u * C::NTHR;
+                const int ec = (C::XS_TOTAL % C::NTHR != 0 && e >= C::XS_TOTAL) ? C::XS_TOTAL - 1 : e;
                 const int cl = ec / C::XT;
                 const int xi = ec - cl * C::XT;
                 const int g = t_in0 + xi;
                 float q = (g >= 0 && g < Tin) ? xs[u] : 0.0f;
                 if (snake_in) q = det_snake(q, Al[ci0 + cl], Al[Cin + ci0 + cl]);
-                if (C::XS_TOTAL % 256 == 0 || e < C::XS_TOTAL) xdst[cl * C::XTP + xi] = q;
+                if (C::XS_TOTAL % C::NTHR == 0 || e < C::XS_TOTAL) xdst[cl * C::XTP + xi] = q;
             }
         }
     }
 };
 
-template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE, bool VEC, bool FUSE>
+template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, int UPS, bool VEC, bool FUSE>
 __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
 {
-    using C = ConvCfg<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE>;
+    using C = ConvCfg<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ws = smem;                          // [2][KC][BM]
     float* const Xs = smem + 2 * C::W_FLOATS;        // [2][CK][XTP]
@@ -215,14 +216,14 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     }
 #endif
     if (snake_in) {
-        for (int c = tid; c < Cin; c += 256) {
+        for (int c = tid; c < Cin; c += C::NTHR) {
             const float al = a.alpha_in[c];
             Al[c] = al;
             Al[Cin + c] = 1.0f / (al + 1e-9f);
         }
     }
 
-    ConvTile<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE, VEC> tile;
+    ConvTile<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS, VEC> tile;
     tile.wp = a.wp; tile.xb = a.x + (size_t)b * Cin * a.Tin; tile.Al = Al; tile.Ws = Ws; tile.Xs = Xs;
     tile.tid = tid; tile.Tin = a.Tin; tile.Cin = Cin; tile.Mpad = a.Mpad; tile.m0 = m0; tile.t_in0 = t_in0;
     tile.g_al = g_al; tile.snake_in = snake_in;
@@ -364,10 +365,10 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     // tanh and the global stores run row-contiguous: 16-byte residual loads and stores when rows are aligned,
     // 4-byte but fully coalesced otherwise.  (ConvTranspose phases whose count does not divide BM keep the
     // direct per-lane store.)
-    const bool has_res = !SHUFFLE && a.residual != nullptr;
+    const bool has_res = (UPS == 0) && a.residual != nullptr;
     const bool snake_out = a.alpha_out != nullptr;
     const bool do_tanh = a.act == 1;
-    const bool direct = SHUFFLE && (C::BM % a.up_s != 0);
+    const bool direct = (UPS != 0) && (C::BM % (UPS ? UPS : 1) != 0);
     if (direct) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -377,7 +378,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 const int m = m0 + (wm * MT + i) * 32 + row;
                 const bool mok = m < a.Mrows;
                 const int mc = mok ? m : a.Mrows - 1;
-                const int co = mc / a.up_s, rr = mc - co * a.up_s;
+                const int co = mc / (UPS ? UPS : 1), rr = mc - co * (UPS ? UPS : 1);
                 const float bv = ep_bias ? ep_bias[co] : 0.0f;
                 float al = 1.0f, inv = 1.0f;
                 if (snake_out) { al = a.alpha_out[co]; inv = 1.0f / (al + 1e-9f); }
@@ -385,7 +386,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int n = n0 + (wn * NT + j) * 32 + l31;
-                    int t = n * a.up_s + rr - a.up_p;
+                    int t = n * (UPS ? UPS : 1) + rr - a.up_p;
                     const bool ok = mok && n < a.Ncols && t >= 0 && t < a.Tout;
                     t = ok ? t : 0;
                     float v = acc[i][j][r] + bv;
@@ -409,11 +410,11 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         }
     __syncthreads();
 
-    if (!SHUFFLE) {
+    if (UPS == 0) {
         if (a.ovec4) {
             constexpr int NV = C::BM * C::BN / 4;
 #pragma unroll 4
-            for (int e = tid; e < NV; e += 256) {
+            for (int e = tid; e < NV; e += C::NTHR) {
                 const int row = e / (C::BN / 4);
                 const int c4 = e - row * (C::BN / 4);
                 const int m = m0 + row, n = n0 + 4 * c4;
@@ -438,7 +439,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         } else {
             constexpr int NE = C::BM * C::BN;
 #pragma unroll 4
-            for (int e = tid; e < NE; e += 256) {
+            for (int e = tid; e < NE; e += C::NTHR) {
                 const int row = e / C::BN;
                 const int col = e - row * C::BN;
                 const int m = m0 + row, n = n0 + col;
@@ -454,12 +455,12 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         }
     } else {
         // pixel shuffle: for each output channel of this tile the S phases interleave into one contiguous run
-        const int S = a.up_s;
+        constexpr int S = UPS ? UPS : 1;
         const int run = C::BN * S;                    // output samples per channel covered by this tile
         const int nco = C::BM / S;
         const int t_base = n0 * S - a.up_p;
         const int total = nco * run;
-        for (int e = tid; e < total; e += 256) {
+        for (int e = tid; e < total; e += C::NTHR) {
             const int col = e / run;
             const int tl = e - col * run;
             const int nl = tl / S, rr = tl - nl * S;
@@ -476,25 +477,25 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
 
 // 16-byte input rows (Tin % 4 == 0) take the float4 staging path; the two paths are separate loop nests so that
 // no control-flow merge sits between a chunk's global loads and the MFMAs that hide them.
-template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE>
-__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a)
+template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, int UPS>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 2) void conv1d_mfma_kernel(const ConvArgs a)
 {
-    if (a.vec4) conv1d_mfma_body<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE, true, false>(a);
-    else conv1d_mfma_body<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE, false, false>(a);
+    if (a.vec4) conv1d_mfma_body<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS, true, false>(a);
+    else conv1d_mfma_body<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS, false, false>(a);
 }
 
 // whole ResidualUnit (7-tap dilated conv + Snake + 1x1 conv + skip) for C == BM
 template <int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, 2) void residual_unit_kernel(const ConvArgs a)
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 2) void residual_unit_kernel(const ConvArgs a)
 {
-    if (a.vec4) conv1d_mfma_body<7, 1, DIL, CK, MT, NT, WAVES_M, WAVES_N, false, true, true>(a);
-    else conv1d_mfma_body<7, 1, DIL, CK, MT, NT, WAVES_M, WAVES_N, false, false, true>(a);
+    if (a.vec4) conv1d_mfma_body<7, 1, DIL, CK, MT, NT, WAVES_M, WAVES_N, 0, true, true>(a);
+    else conv1d_mfma_body<7, 1, DIL, CK, MT, NT, WAVES_M, WAVES_N, 0, false, true>(a);
 }
 
 template <int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N>
 inline hipError_t launch_residual_unit(const ConvArgs& a_in, hipStream_t stream)
 {
-    using C = ConvCfg<7, 1, DIL, CK, MT, NT, WAVES_M, WAVES_N, false>;
+    using C = ConvCfg<7, 1, DIL, CK, MT, NT, WAVES_M, WAVES_N, 0>;
     ConvArgs a = a_in;
     if (a.Cin % CK != 0 || a.Cout != C::BM || a.Cin != C::BM || a.Mpad != C::BM) return hipErrorInvalidValue;
     a.n_tiles = (a.Ncols + C::BN - 1) / C::BN;
@@ -511,14 +512,14 @@ inline hipError_t launch_residual_unit(const ConvArgs& a_in, hipStream_t stream)
         attr_set = true;
     }
     dim3 grid((unsigned)(a.n_tiles * a.B), 1);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), lds, stream, a);
     return hipGetLastError();
 }
 
-template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, bool SHUFFLE>
+template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, int UPS>
 inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
 {
-    using C = ConvCfg<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE>;
+    using C = ConvCfg<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS>;
     ConvArgs a = a_in;
     if (a.Cin % CK != 0) return hipErrorInvalidValue;
     a.n_tiles = (a.Ncols + C::BN - 1) / C::BN;
@@ -526,7 +527,7 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
     a.ovec4 = (a.Tout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
               (!a.residual || (reinterpret_cast<uintptr_t>(a.residual) & 15) == 0);
     const size_t lds = (size_t)C::LDS_FLOATS * 4 + (a.alpha_in ? (size_t)2 * a.Cin * 4 : 0);
-    auto kern = conv1d_mfma_kernel<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, SHUFFLE>;
+    auto kern = conv1d_mfma_kernel<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -536,7 +537,7 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid((unsigned)(a.n_tiles * a.B), (unsigned)((a.Mrows + C::BM - 1) / C::BM));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -5,13 +5,14 @@ hipError_t launch_conv_k1k3(const ConvArgs& a, int ks, int bm, hipStream_t s)
 {
     if (ks == 1) {
         switch (bm) {
-            case 128: return launch_conv1d_mfma<1, 1, 1, 32, 2, 2, 2, 2, false>(a, s);
-            case 96:  return launch_conv1d_mfma<1, 1, 1, 32, 3, 1, 1, 4, false>(a, s);
-            case 64:  return launch_conv1d_mfma<1, 1, 1, 32, 2, 2, 1, 4, false>(a, s);
+            case 128: return launch_conv1d_mfma<1, 1, 1, 32, 2, 2, 2, 2, 0>(a, s);
+            case 96:  return launch_conv1d_mfma<1, 1, 1, 32, 3, 1, 1, 4, 0>(a, s);
+            case 64:  return launch_conv1d_mfma<1, 1, 1, 32, 2, 2, 1, 4, 0>(a, s);
         }
     } else if (ks == 3) {
+        if (bm == 128 && a.Ncols <= 96) return launch_conv1d_mfma<3, 1, 1, 16, 1, 3, 4, 1, 0>(a, s);
         switch (bm) {
-            case 128: return launch_conv1d_mfma<3, 1, 1, 16, 2, 2, 2, 2, false>(a, s);
+            case 128: return launch_conv1d_mfma<3, 1, 1, 16, 2, 2, 2, 2, 0>(a, s);
         }
     }
     return hipErrorInvalidValue;

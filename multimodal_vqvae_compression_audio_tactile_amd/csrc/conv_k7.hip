@@ -1,13 +1,18 @@
 // conv_k7.hip -- ResidualUnit 7-tap dilated convs (75 % of the path's FLOPs) + decoder input conv.
+#ifndef MVQ_K7_TILE
+#define MVQ_K7_TILE 2, 2, 2, 2
+#endif
 #include "conv_dispatch.hpp"
 namespace mvq {
 template <int DIL>
 static hipError_t k7(const ConvArgs& a, int bm, hipStream_t s)
 {
+    if (DIL == 1 && bm == 128 && a.Ncols <= 96)          // latent-rate layer (T = 75): 128 x 96 tile instead of 128 x 128
+        return launch_conv1d_mfma<7, 1, 1, 8, 1, 3, 4, 1, 0>(a, s);
     switch (bm) {
-        case 128: return launch_conv1d_mfma<7, 1, DIL, 8, 2, 2, 2, 2, false>(a, s);
-        case 96:  return launch_conv1d_mfma<7, 1, DIL, 8, 3, 1, 1, 4, false>(a, s);
-        case 64:  return launch_conv1d_mfma<7, 1, DIL, 8, 2, 2, 1, 4, false>(a, s);
+        case 128: return launch_conv1d_mfma<7, 1, DIL, 8, MVQ_K7_TILE, 0>(a, s);
+        case 96:  return launch_conv1d_mfma<7, 1, DIL, 8, 3, 1, 1, 4, 0>(a, s);
+        case 64:  return launch_conv1d_mfma<7, 1, DIL, 8, 2, 2, 1, 4, 0>(a, s);
     }
     return hipErrorInvalidValue;
 }

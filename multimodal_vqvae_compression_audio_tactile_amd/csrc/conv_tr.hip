@@ -4,10 +4,16 @@
 namespace mvq {
 hipError_t launch_conv_tr(const ConvArgs& a, int bm, hipStream_t s)
 {
-    switch (bm) {
-        case 128: return launch_conv1d_mfma<2, 1, 1, 32, 2, 2, 2, 2, true>(a, s);
-        case 96:  return launch_conv1d_mfma<2, 1, 1, 32, 3, 1, 1, 4, true>(a, s);
-        case 64:  return launch_conv1d_mfma<2, 1, 1, 32, 2, 2, 1, 4, true>(a, s);
+    const bool narrow = bm == 128 && a.Ncols <= 96;
+    switch (a.up_s) {
+        case 8: if (bm == 128) return narrow ? launch_conv1d_mfma<2, 1, 1, 32, 1, 3, 4, 1, 8>(a, s)
+                                              : launch_conv1d_mfma<2, 1, 1, 32, 2, 2, 2, 2, 8>(a, s);
+                break;
+        case 5: if (bm == 128) return launch_conv1d_mfma<2, 1, 1, 32, 2, 2, 2, 2, 5>(a, s); break;
+        case 4: if (bm == 128) return launch_conv1d_mfma<2, 1, 1, 32, 2, 2, 2, 2, 4>(a, s); break;
+        case 2: if (bm == 96) return launch_conv1d_mfma<2, 1, 1, 32, 3, 1, 1, 4, 2>(a, s);
+                if (bm == 128) return launch_conv1d_mfma<2, 1, 1, 32, 2, 2, 2, 2, 2>(a, s);
+                break;
     }
     return hipErrorInvalidValue;
 }

@@ -197,10 +197,26 @@ __global__ __launch_bounds__(256) void layernorm_c_tile_kernel(
     __syncthreads();
     if (tid < LN_TOK) {
         float s = 0.0f;
-        for (int c = 0; c < C; ++c) s = s + tile[c * LN_TOK + tid];
+        int c = 0;
+        for (; c + 16 <= C; c += 16) {                            // operands first, then the (ordered) chain
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = tile[(c + u) * LN_TOK + tid];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s = s + v[u];
+        }
+        for (; c < C; ++c) s = s + tile[c * LN_TOK + tid];
         const float mean = s / (float)C;
         float var = 0.0f;
-        for (int c = 0; c < C; ++c) { const float d = tile[c * LN_TOK + tid] - mean; var = dfma(d, d, var); }
+        c = 0;
+        for (; c + 16 <= C; c += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = tile[(c + u) * LN_TOK + tid];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const float d = v[u] - mean; var = dfma(d, d, var); }
+        }
+        for (; c < C; ++c) { const float d = tile[c * LN_TOK + tid] - mean; var = dfma(d, d, var); }
         mean_s[tid] = mean;
         rstd_s[tid] = 1.0f / __builtin_sqrtf(var / (float)C + eps);
     }
@@ -277,40 +293,62 @@ hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamm
 }
 
 // ------------------------------------------------------------------------------------------------
-// attention core: one thread per (b, head, query); probabilities live in LDS (Tk floats per thread).
+// attention core: one block per (batch element, head).  Q, K, V head slices are staged in LDS; one thread per
+// (query, key) pair walks the dh-long score chain, Tq threads do the (ordered) softmax rows, then one thread per
+// (channel, query) output walks the Tk-long value chain.  Tq, Tk <= 64.
 // ------------------------------------------------------------------------------------------------
-__global__ void attention_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                 const float* __restrict__ V, float* __restrict__ ctx,
-                                 int B, int H, int dh, int Tq, int Tk,
-                                 size_t qsb, size_t qsc, size_t ksb, size_t ksc)
+__global__ __launch_bounds__(256) void attention_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, float* __restrict__ ctx,
+    int B, int H, int dh, int Tq, int Tk, size_t qsb, size_t qsc, size_t ksb, size_t ksc)
 {
-    extern __shared__ float pbuf[];                     // [blockDim.x][Tk]
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= B * H * Tq) return;
-    const int i = n % Tq;
-    const int bh = n / Tq;
-    const int hd = bh % H, b = bh / H;
-    const float* q = Q + (size_t)b * qsb + (size_t)hd * dh * qsc + i;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm;                       // [dh][Tq]
+    float* Ks = Qs + dh * Tq;             // [dh][Tk]
+    float* Vs = Ks + dh * Tk;             // [dh][Tk]
+    float* P = Vs + dh * Tk;              // [Tq][Tk]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / H, hd = blockIdx.x - b * H;
+    const float* q = Q + (size_t)b * qsb + (size_t)hd * dh * qsc;
     const float* kb = K + (size_t)b * ksb + (size_t)hd * dh * ksc;
     const float* vb = V + (size_t)b * ksb + (size_t)hd * dh * ksc;
-    float* p = pbuf + (size_t)threadIdx.x * Tk;
-    const float rs = __builtin_sqrtf((float)dh);
-    float m = -__builtin_inff();
-    for (int j = 0; j < Tk; ++j) {
-        float a = 0.0f;
-        for (int d = 0; d < dh; ++d) a = dfma(q[(size_t)d * qsc], kb[(size_t)d * ksc + j], a);
-        a = a / rs;
-        p[j] = a;
-        m = __builtin_fmaxf(m, a);
+    for (int e = tid; e < dh * Tq; e += 256) { const int d = e / Tq, i = e - d * Tq; Qs[e] = q[(size_t)d * qsc + i]; }
+    for (int e = tid; e < dh * Tk; e += 256) {
+        const int d = e / Tk, j = e - d * Tk;
+        Ks[e] = kb[(size_t)d * ksc + j];
+        Vs[e] = vb[(size_t)d * ksc + j];
     }
-    float l = 0.0f;
-    for (int j = 0; j < Tk; ++j) { const float e = det_exp(p[j] - m); p[j] = e; l = l + e; }
-    for (int j = 0; j < Tk; ++j) p[j] = p[j] / l;
-    float* out = ctx + (size_t)b * qsb + (size_t)hd * dh * qsc + i;
-    for (int d = 0; d < dh; ++d) {
+    __syncthreads();
+    const float rs = __builtin_sqrtf((float)dh);
+    for (int p = tid; p < Tq * Tk; p += 256) {
+        const int i = p / Tk, j = p - i * Tk;
         float a = 0.0f;
-        for (int j = 0; j < Tk; ++j) a = dfma(p[j], vb[(size_t)d * ksc + j], a);
-        out[(size_t)d * qsc] = a;
+        int d = 0;
+        for (; d + 8 <= dh; d += 8) {
+            float qv[8], kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { qv[u] = Qs[(d + u) * Tq + i]; kv[u] = Ks[(d + u) * Tk + j]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = dfma(qv[u], kv[u], a);
+        }
+        for (; d < dh; ++d) a = dfma(Qs[d * Tq + i], Ks[d * Tk + j], a);
+        P[p] = a / rs;
+    }
+    __syncthreads();
+    if (tid < Tq) {
+        float* pr = P + tid * Tk;
+        float m = -__builtin_inff();
+        for (int j = 0; j < Tk; ++j) m = __builtin_fmaxf(m, pr[j]);
+        float l = 0.0f;
+        for (int j = 0; j < Tk; ++j) { const float e = det_exp(pr[j] - m); pr[j] = e; l = l + e; }
+        for (int j = 0; j < Tk; ++j) pr[j] = pr[j] / l;
+    }
+    __syncthreads();
+    float* out = ctx + (size_t)b * qsb + (size_t)hd * dh * qsc;
+    for (int e = tid; e < dh * Tq; e += 256) {
+        const int d = e / Tq, i = e - d * Tq;
+        float a = 0.0f;
+        for (int j = 0; j < Tk; ++j) a = dfma(P[i * Tk + j], Vs[d * Tk + j], a);
+        out[(size_t)d * qsc + i] = a;
     }
 }
 
@@ -318,11 +356,10 @@ hipError_t launch_attention(const float* q, const float* k, const float* v, floa
                             int B, int H, int dh, int Tq, int Tk, size_t qsb, size_t qsc, size_t ksb, size_t ksc,
                             hipStream_t s)
 {
-    const int n = B * H * Tq;
-    if (n == 0) return hipSuccess;
-    const int threads = 64;
-    hipLaunchKernelGGL(attention_kernel, dim3((n + threads - 1) / threads), dim3(threads),
-                       (size_t)threads * (Tk > 0 ? Tk : 1) * sizeof(float), s, q, k, v, ctx, B, H, dh, Tq, Tk,
+    if (B * H * Tq == 0) return hipSuccess;
+    const size_t lds = ((size_t)dh * (Tq + 2 * Tk) + (size_t)Tq * Tk) * sizeof(float);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attention_kernel, dim3(B * H), dim3(256), lds, s, q, k, v, ctx, B, H, dh, Tq, Tk,
                        qsb, qsc, ksb, ksc);
     return hipGetLastError();
 }

@@ -127,11 +127,15 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_kernel(
                 for (int u = 0; u < 2; ++u) { bs[u] = -__builtin_inff(); bi[u] = 0x7fffffff; }
                 for (int kk = lane; kk < kh; kk += 64) {
                     float dot0 = 0.0f, dot1 = 0.0f;
-                    for (int d = 0; d < D; ++d) {
-                        const float e = Et[d * KHP + kk];
-                        const float2 r = *reinterpret_cast<const float2*>(resT + d * RVQ_TOKS + tok0);
-                        dot0 = dfma(r.x, e, dot0);
-                        dot1 = dfma(r.y, e, dot1);
+                    for (int d = 0; d < D; d += 4) {                // D % 4 == 0; operands first, then the chains
+                        float e[4]; float2 r[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            e[u] = Et[(d + u) * KHP + kk];
+                            r[u] = *reinterpret_cast<const float2*>(resT + (d + u) * RVQ_TOKS + tok0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { dot0 = dfma(r[u].x, e[u], dot0); dot1 = dfma(r[u].y, e[u], dot1); }
                     }
                     const float h = hn[kk];
                     const float sc0 = dot0 - h, sc1 = dot1 - h;
@@ -299,7 +303,13 @@ __global__ __launch_bounds__(256) void dac_rvq_kernel(
         if (grp < Dc) {
             const float* wr = wst + (size_t)grp * C;
             float a = 0.0f;
-            for (int c = 0; c < C; ++c) a = dfma(wr[c], res[c * DQ_TOK + tok], a);
+            for (int c = 0; c < C; c += 16) {                       // C % 16 == 0; operands first, then the chain
+                float wv[16], rv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { wv[u] = wr[c + u]; rv[u] = res[(c + u) * DQ_TOK + tok]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a = dfma(wv[u], rv[u], a);
+            }
             const float v = a + in_b[(size_t)st * Dc + grp];
             ze[grp * DQ_TOK + tok] = v;
             if (live) latents[((size_t)bb * nq * Dc + (size_t)st * Dc + grp) * T + tt] = v;

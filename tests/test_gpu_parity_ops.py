@@ -40,6 +40,8 @@ CONV_CASES = [
     (2, 96, 900, 1, 7, 1, 1, 3, False, False, False, True),      # decoder output conv + tanh (direct)
     (1, 1024, 40, 8, 1, 1, 1, 0, False, False, False, False),    # tiny Cout (direct)
     (1, 40, 100, 24, 5, 2, 2, 3, True, False, True, False),      # odd shape -> direct fallback
+    (2, 1024, 75, 1536, 7, 1, 1, 3, False, False, True, False),  # decoder input conv: narrow 128x96 tile
+    (2, 512, 600, 1024, 16, 8, 1, 4, False, False, True, False), # last encoder down-sampling conv (Tout = 75)
 ]
 
 
@@ -74,6 +76,8 @@ CONVTR_CASES = [
     (1, 384, 130, 192, 4, True, True),
     (2, 192, 301, 96, 2, True, False),
     (1, 48, 33, 20, 3, True, False),     # direct fallback
+    (2, 1536, 75, 768, 8, False, False), # dec.b0 up-sampling at the latent rate (narrow tile), pre-snaked input
+    (1, 256, 40, 128, 2, True, True),    # stride 2 with a 128-row tile
 ]
 
 
