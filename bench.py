@@ -102,12 +102,26 @@ class KernelEvents:
         return {k: {"seconds": v[0], "flops": v[1], "launches": v[2]} for k, v in tot.items()}
 
 
+def host_cores() -> int:
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota) -- the GPU box hands each job a CPU
+    share (16 for one GPU); running torch with one thread per visible core (256) oversubscribes it badly."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(workload, books, embed, sd):
     """torch-CPU restatement on the host cores: bounded sample (B=6, the reference batch; 1 warm-up + timed reps
     until ~15 s)."""
     from oracle import dac24_torch as T
     from multimodal_vqvae_compression_audio_tactile_amd import synth
-    threads = torch.get_num_threads()
+    threads = host_cores()
+    torch.set_num_threads(threads)
     net = T.ProposedEval(rvq_books=books, rvq_embed=embed).eval()
     missing = net.load_state_dict(sd, strict=True)
     B = 6
@@ -116,7 +130,7 @@ def cpu_baseline(workload, books, embed, sd):
     with torch.no_grad():
         t0 = time.perf_counter(); net.forward_eval(a[:1], t[:1], tactile_only=tact); warm = time.perf_counter() - t0
         reps, spent = 0, 0.0
-        while spent < 15.0 and reps < 10:
+        while spent < 12.0 and reps < 10:
             t0 = time.perf_counter(); net.forward_eval(a, t, tactile_only=tact); spent += time.perf_counter() - t0
             reps += 1
     seg_s = B * reps / spent
