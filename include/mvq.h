@@ -115,8 +115,10 @@ int mvq_rvq_ema_step_f32(const float* z_tokens, float* books, void* scratch,
 /* dac ResidualVectorQuantize.forward in eval mode, first nq_use stages
  * (`qa, *_ = self.A_QUANT(za)` Training/compare_dacvsproposal_5.py:295; `mdl.encode(x, n_quantizers)`
  * Evaluation/compare_dacvsproposal_5_eval.py:369).  Weights already weight-norm folded:
- *   in_w[nq,Dc,C], in_b[nq,Dc], codebook[nq,K,Dc], out_w[nq,C,Dc], out_b[nq,C]   (Dc <= 16).
- *   z[B,C,T] -> zq[B,C,T], codes[B,nq_use,T] (int32), latents[B,nq_use*Dc,T]. */
+ *   in_w[nq,Dc,C], in_b[nq,Dc], codebook[nq,K,Dc], out_w[nq,C,Dc], out_b[nq,C].
+ *   z[B,C,T] -> zq[B,C,T], codes[B,nq_use,T] (int32), latents[B,nq_use*Dc,T].   C in {256, 512, 1024}, Dc = 8.
+ * Summation order of in_proj (the only C-long reduction here): 16 block partials over C/16 contiguous channels
+ * (each an fma chain from +0), added in block order, then + bias; out_proj: fma chain over Dc, then + bias. */
 int mvq_dac_rvq_f32(const float* z, const float* in_w, const float* in_b, const float* codebook,
                     const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
                     int batch, int c, int t, int nq_use, int k, int dc, void* stream);

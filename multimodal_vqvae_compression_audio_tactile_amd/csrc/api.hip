@@ -245,9 +245,9 @@ int mvq_dac_rvq_f32(const float* z, const float* in_w, const float* in_b, const 
 {
     if (!z || !zq || !codes || !latents || !in_w || !in_b || !codebook || !out_w || !out_b)
         return fail(MVQ_EINVAL, "dac_rvq: null tensor");
-    if (batch < 0 || t < 0 || c <= 0 || c % 16 != 0 || c > 1024 || nq_use <= 0 || k <= 0 || dc <= 0 || dc > 16)
-        return fail(MVQ_EINVAL, "dac_rvq: bad shape B=%d C=%d T=%d nq=%d K=%d Dc=%d", batch, c, t, nq_use, k, dc);
-    const size_t lds = ((size_t)c * 16 + (size_t)k * dc + k + 3 * (size_t)dc * 16 + 16 + 2 * 16 * 16 + (size_t)dc * c) * sizeof(float);
+    if (batch < 0 || t < 0 || (c != 1024 && c != 512 && c != 256) || dc != 8 || (k * dc) % 4 != 0 || nq_use <= 0 || k <= 0 || dc <= 0 || dc > 16)
+        return fail(MVQ_EINVAL, "dac_rvq: bad shape B=%d C=%d T=%d nq=%d K=%d Dc=%d (C in {256,512,1024}, Dc = 8)", batch, c, t, nq_use, k, dc);
+    const size_t lds = ((size_t)k * dc + k + (size_t)dc * c + 16 * (size_t)dc * 16 + 2 * (size_t)dc * 16 + 2 * 16 * 16) * sizeof(float);
     if (lds > 160 * 1024) return fail(MVQ_EUNSUPPORTED, "dac_rvq: K*Dc too large for LDS (%zu bytes)", lds);
     hipError_t e = mvq::launch_dac_rvq(z, in_w, in_b, codebook, out_w, out_b, zq, codes, latents, batch, c, t, nq_use, k, dc, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "dac_rvq");

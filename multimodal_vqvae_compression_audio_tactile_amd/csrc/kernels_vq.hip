@@ -8,7 +8,7 @@
 //  (2) rvq_assign / ema_update: ResidualVQEMA.ema_step (deterministic token-order sums).
 //  (3) dac_rvq: the 32-stage DAC residual quantiser (K = 1024, Dc = 8) fused into ONE launch: in_proj, L2
 //      normalisation, cosine search against the LDS-resident normalised codebook, straight-through out_proj
-//      and residual update, all stages for a block's 16 tokens without leaving the CU.
+//      and residual update, all stages for a block's 16 tokens with the residual held in registers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "det_math.hpp"
@@ -240,54 +240,58 @@ hipError_t launch_ema_update(const float* z, const int32_t* idx, float* books, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// DAC residual VQ, all stages fused.  Block = 256 threads, 16 tokens.
-//   LDS: res[C][16] | cbn[K][Dc] | cn2[K] | ze[Dc][16] | e[Dc][16] | pre[Dc][16] | red_s[16][16] | red_i[16][16] | w[Dc*C]
+// DAC residual VQ, all stages fused.  Block = 256 threads, 16 tokens; thread (grp, tok) OWNS the C/16 contiguous
+// channels [grp*C/16, (grp+1)*C/16) of its token: residual and z_q accumulator live in registers for all stages.
+//   in_proj  : 16 block-partial fma chains (one per thread, over its own channels) summed in block order
+//              (the "blocked" order of the contract, see include/mvq.h), weights staged in LDS per stage
+//   search   : L2-normalised cosine search against the LDS-resident normalised codebook, lane-group arg-max
+//   out_proj : straight-through 8-long chain per owned channel, accumulate + residual update in registers
+//   LDS: cbn[K][Dc] | cn2[K] | w[Dc*C] | part[16][Dc][16] | ze[Dc][16] | pre[Dc][16] | red_s[16][16] | red_i[16][16]
 // ------------------------------------------------------------------------------------------------
 constexpr int DQ_TOK = 16;
 
-__global__ __launch_bounds__(256) void dac_rvq_kernel(
+template <int CPT, int DC>    // channels per thread (C = 16*CPT), codebook dimension
+__global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
     const float* __restrict__ z, const float* __restrict__ in_w, const float* __restrict__ in_b,
     const float* __restrict__ cb, const float* __restrict__ out_w, const float* __restrict__ out_b,
     float* __restrict__ zq, int32_t* __restrict__ codes, float* __restrict__ latents,
-    int B, int C, int T, int nq, int K, int Dc)
+    int B, int T, int nq, int K)
 {
+    constexpr int C = 16 * CPT;
+    constexpr int Dc = DC;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* res = sm;                                   // [C][16]
-    float* cbn = res + (size_t)C * DQ_TOK;             // [K][Dc]
+    float* cbn = sm;                                   // [K][Dc]
     float* cn2 = cbn + (size_t)K * Dc;                 // [K]
-    float* ze = cn2 + K;                               // [Dc][16]
-    float* en = ze + Dc * DQ_TOK;                      // [Dc][16]
-    float* pre = en + Dc * DQ_TOK;                     // [Dc][16]
-    float* en2 = pre + Dc * DQ_TOK;                    // [16]
-    float* red_s = en2 + DQ_TOK;                       // [16 groups][16 tok]
+    float* wst = cn2 + K;                              // [Dc*C]
+    float* part = wst + (size_t)Dc * C;                // [16][Dc][16]
+    float* ze = part + 16 * Dc * DQ_TOK;               // [Dc][16]
+    float* pre = ze + Dc * DQ_TOK;                     // [Dc][16]
+    float* red_s = pre + Dc * DQ_TOK;                  // [16][16]
     int* red_i = reinterpret_cast<int*>(red_s + 16 * DQ_TOK);
-    float* wst = reinterpret_cast<float*>(red_i + 16 * DQ_TOK);   // [Dc*C]: in_proj weights, then out_proj weights
 
     const int tid = threadIdx.x;
     const int tok = tid & 15;
     const int grp = tid >> 4;                          // 0..15
     const int N = B * T;
-    const int n0 = blockIdx.x * DQ_TOK;
-    const int n = n0 + tok;
+    const int n = blockIdx.x * DQ_TOK + tok;
     const bool live = n < N;
     const int bb = live ? n / T : 0, tt = live ? n - bb * T : 0;
+    const int c0 = grp * CPT;
 
-    const int CPT = C / 16;                            // channels per thread (c = grp + 16*j)
-    float acc[64];                                     // C <= 1024
+    float res[CPT], acc[CPT];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) acc[j] = 0.0f;
-
     for (int j = 0; j < CPT; ++j) {
-        const int c = grp + 16 * j;
-        res[c * DQ_TOK + tok] = live ? z[((size_t)bb * C + c) * T + tt] : 0.0f;
+        acc[j] = 0.0f;
+        res[j] = live ? z[((size_t)bb * C + c0 + j) * T + tt] : 0.0f;
     }
 
     for (int st = 0; st < nq; ++st) {
-        __syncthreads();
-        // normalised codebook of this stage: raw rows -> LDS (batched 16-byte loads), then normalise in place
         const float* cbs = cb + (size_t)st * K * Dc;
+        __syncthreads();                               // previous stage done with cbn / wst
         copy_to_lds_f4(cbn, cbs, K * Dc, tid);
+        copy_to_lds_f4(wst, in_w + (size_t)st * Dc * C, Dc * C, tid);
         __syncthreads();
+        // normalised codebook (in place) + squared norms
         for (int k = tid; k < K; k += 256) {
             float ss = 0.0f;
             for (int d = 0; d < Dc; ++d) { const float v = cbn[k * Dc + d]; ss = dfma(v, v, ss); }
@@ -296,43 +300,48 @@ __global__ __launch_bounds__(256) void dac_rvq_kernel(
             for (int d = 0; d < Dc; ++d) { const float v = cbn[k * Dc + d] / den; cbn[k * Dc + d] = v; s2 = dfma(v, v, s2); }
             cn2[k] = s2;
         }
-        // stage this stage's in_proj weights [Dc][C] in LDS (a chain fed by global loads runs at memory latency)
-        copy_to_lds_f4(wst, in_w + (size_t)st * Dc * C, Dc * C, tid);
-        __syncthreads();
-        // in_proj: thread (d = grp < Dc, tok): chain over C
-        if (grp < Dc) {
-            const float* wr = wst + (size_t)grp * C;
-            float a = 0.0f;
-            for (int c = 0; c < C; c += 16) {                       // C % 16 == 0; operands first, then the chain
-                float wv[16], rv[16];
+        // in_proj block partials: this thread's channels, every codebook dimension
 #pragma unroll
-                for (int u = 0; u < 16; ++u) { wv[u] = wr[c + u]; rv[u] = res[(c + u) * DQ_TOK + tok]; }
+        for (int d = 0; d < Dc; ++d) {
+            const float* wr = wst + (size_t)d * C + c0;
+            float p = 0.0f;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) a = dfma(wv[u], rv[u], a);
+            for (int j = 0; j < CPT; j += 4) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wr + j);
+                p = dfma(w4.x, res[j], p); p = dfma(w4.y, res[j + 1], p);
+                p = dfma(w4.z, res[j + 2], p); p = dfma(w4.w, res[j + 3], p);
             }
+            part[(grp * Dc + d) * DQ_TOK + tok] = p;
+        }
+        __syncthreads();
+        if (grp < Dc) {                                // d = grp: sum the 16 block partials in block order, + bias
+            float a = part[(0 * Dc + grp) * DQ_TOK + tok];
+#pragma unroll
+            for (int g = 1; g < 16; ++g) a = a + part[(g * Dc + grp) * DQ_TOK + tok];
             const float v = a + in_b[(size_t)st * Dc + grp];
             ze[grp * DQ_TOK + tok] = v;
             if (live) latents[((size_t)bb * nq * Dc + (size_t)st * Dc + grp) * T + tt] = v;
         }
         __syncthreads();
-        // out_proj weights [C][Dc] replace the in_proj weights in LDS (used after the search)
+        // out_proj weights [C][Dc] replace the in_proj weights (every in_proj read is behind the barrier above)
         copy_to_lds_f4(wst, out_w + (size_t)st * C * Dc, Dc * C, tid);
-        // F.normalize over Dc (every thread of a token computes the same values)
         {
+            // F.normalize over Dc (every thread of a token computes the same values)
             float ss = 0.0f;
             for (int d = 0; d < Dc; ++d) { const float v = ze[d * DQ_TOK + tok]; ss = dfma(v, v, ss); }
             const float den = __builtin_fmaxf(__builtin_sqrtf(ss), 1e-12f);
             float s2 = 0.0f;
-            float ev[16];
+            float ev[Dc];
 #pragma unroll
-            for (int d = 0; d < 16; ++d) if (d < Dc) { ev[d] = ze[d * DQ_TOK + tok] / den; s2 = dfma(ev[d], ev[d], s2); }
+            for (int d = 0; d < Dc; ++d) { ev[d] = ze[d * DQ_TOK + tok] / den; s2 = dfma(ev[d], ev[d], s2); }
             // search: this thread scans codes k = grp + 16*j
             float bs = -__builtin_inff(); int bi = 0x7fffffff;
+#pragma unroll 4
             for (int k = grp; k < K; k += 16) {
                 const float* ck = cbn + k * Dc;
                 float dot = 0.0f;
 #pragma unroll
-                for (int d = 0; d < 16; ++d) if (d < Dc) dot = dfma(ev[d], ck[d], dot);
+                for (int d = 0; d < Dc; ++d) dot = dfma(ev[d], ck[d], dot);
                 const float dist = (s2 - 2.0f * dot) + cn2[k];
                 const float sc = -dist;
                 if (sc > bs) { bs = sc; bi = k; }
@@ -350,52 +359,61 @@ __global__ __launch_bounds__(256) void dac_rvq_kernel(
             for (int d = 0; d < Dc; ++d) { const float zv = ze[d * DQ_TOK + tok]; pre[d * DQ_TOK + tok] = zv + (raw[d] - zv); }
         }
         __syncthreads();
-        // out_proj + accumulate + residual update: thread owns channels c = grp + 16*j of its token
         {
-            float pv[16];
+            float pv[Dc];
 #pragma unroll
-            for (int d = 0; d < 16; ++d) if (d < Dc) pv[d] = pre[d * DQ_TOK + tok];
-            const float* ow = wst;
-            const float* ob = out_b + (size_t)st * C;
+            for (int d = 0; d < Dc; ++d) pv[d] = pre[d * DQ_TOK + tok];
+            const float* ob = out_b + (size_t)st * C + c0;
 #pragma unroll
-            for (int j = 0; j < 64; ++j) {
-                if (j < CPT) {
-                    const int c = grp + 16 * j;
-                    const float* wr = ow + (size_t)c * Dc;
-                    float a = 0.0f;
+            for (int j = 0; j < CPT; ++j) {
+                const float* wr = wst + (size_t)(c0 + j) * Dc;
+                float a = 0.0f;
 #pragma unroll
-                    for (int d = 0; d < 16; ++d) if (d < Dc) a = dfma(wr[d], pv[d], a);
-                    const float zqi = a + ob[c];
-                    acc[j] = acc[j] + zqi;
-                    res[c * DQ_TOK + tok] = res[c * DQ_TOK + tok] - zqi;
-                }
+                for (int d = 0; d < Dc; ++d) a = dfma(wr[d], pv[d], a);
+                const float zqi = a + ob[j];
+                acc[j] = acc[j] + zqi;
+                res[j] = res[j] - zqi;
             }
         }
     }
     if (live) {
 #pragma unroll
-        for (int j = 0; j < 64; ++j)
-            if (j < CPT) zq[((size_t)bb * C + grp + 16 * j) * T + tt] = acc[j];
+        for (int j = 0; j < CPT; ++j) zq[((size_t)bb * C + c0 + j) * T + tt] = acc[j];
     }
+}
+
+template <int CPT, int DC>
+static hipError_t launch_dac_rvq_t(const float* z, const float* in_w, const float* in_b, const float* cb,
+                                   const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
+                                   int B, int T, int nq, int K, hipStream_t s)
+{
+    constexpr int C = 16 * CPT;
+    const int N = B * T;
+    const size_t lds = ((size_t)K * DC + K + (size_t)DC * C + 16 * (size_t)DC * DQ_TOK + 2 * (size_t)DC * DQ_TOK + 2 * 16 * DQ_TOK) * sizeof(float);
+    auto kern = dac_rvq_kernel<CPT, DC>;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((N + DQ_TOK - 1) / DQ_TOK), dim3(256), lds, s,
+                       z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, B, T, nq, K);
+    return hipGetLastError();
 }
 
 hipError_t launch_dac_rvq(const float* z, const float* in_w, const float* in_b, const float* cb, const float* out_w,
                           const float* out_b, float* zq, int32_t* codes, float* latents,
                           int B, int C, int T, int nq, int K, int Dc, hipStream_t s)
 {
-    const int N = B * T;
-    if (N == 0) return hipSuccess;
-    const size_t lds = ((size_t)C * DQ_TOK + (size_t)K * Dc + K + 3 * (size_t)Dc * DQ_TOK + DQ_TOK + 2 * 16 * DQ_TOK + (size_t)Dc * C) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dac_rvq_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
+    if (B * T == 0) return hipSuccess;
+    if (Dc != 8) return hipErrorInvalidValue;
+    switch (C) {
+        case 1024: return launch_dac_rvq_t<64, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, B, T, nq, K, s);
+        case 512:  return launch_dac_rvq_t<32, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, B, T, nq, K, s);
+        case 256:  return launch_dac_rvq_t<16, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, B, T, nq, K, s);
     }
-    hipLaunchKernelGGL(dac_rvq_kernel, dim3((N + DQ_TOK - 1) / DQ_TOK), dim3(256), lds, s,
-                       z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, B, C, T, nq, K, Dc);
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
 }  // namespace mvq

@@ -322,7 +322,8 @@ void orc_rvq_ema_step(const float* X, float* books, int nb, int K, int D, int N,
  * DAC ResidualVectorQuantize.forward (eval mode), restated from the upstream architecture
  * [dac/nn/quantize.py VectorQuantize.forward/decode_latents, ResidualVectorQuantize.forward]:
  *   per stage i < n_q:
- *     z_e   = in_proj_i(residual)                   (1x1 conv C->Dc, weights already WN-folded)
+ *     z_e   = in_proj_i(residual)                   (1x1 conv C->Dc, weights already WN-folded; the C-long
+ *                                                    sum is taken as 16 block partials of C/16 channels)
  *     e     = z_e / max(||z_e||_2, 1e-12)           (F.normalize over the Dc axis, per token)
  *     c_k   = cb_i[k] / max(||cb_i[k]||_2, 1e-12)
  *     dist  = (sum e^2 - 2*(e.c_k)) + sum c_k^2 ;  idx = argmax(-dist) (first max)
@@ -361,9 +362,16 @@ void orc_dac_rvq(const float* z, const float* in_w, const float* in_b, const flo
             for (int c = 0; c < C; ++c) { res[c] = z[((size_t)b * C + c) * T + t]; acc[c] = 0.0f; }
             for (int i = 0; i < nq_use; ++i) {
                 for (int d = 0; d < Dc; ++d) {
+                    /* blocked order: 16 block-partials over C/16 contiguous channels each (fma chain from 0),
+                     * summed in block order, then + bias */
                     const float* wr = in_w + ((size_t)i * Dc + d) * C;
+                    const int cb_ = C / 16;
                     float a = 0.0f;
-                    for (int c = 0; c < C; ++c) a = om_fma(wr[c], res[c], a);
+                    for (int g = 0; g < 16; ++g) {
+                        float p = 0.0f;
+                        for (int c = g * cb_; c < (g + 1) * cb_; ++c) p = om_fma(wr[c], res[c], p);
+                        a = g == 0 ? p : a + p;
+                    }
                     ze[d] = a + in_b[(size_t)i * Dc + d];
                     latents[((size_t)b * nq_use * Dc + (size_t)i * Dc + d) * T + t] = ze[d];
                 }
