@@ -75,7 +75,7 @@ class KernelEvents:
             e0.record()
             y = orig_conv(x, wp, cout, ks, bias=bias, stride=stride, dil=dil, pad=pad, **kw)
             e1.record()
-            rec.append((ops.conv_kernel_name(cin, cout, ks, stride, dil, tin=tin), 2.0 * cin * cout * ks * tout * B, e0, e1))
+            rec.append((ops.conv_kernel_name(cin, cout, ks, stride, dil, tin=tin, batch=B), 2.0 * cin * cout * ks * tout * B, e0, e1))
             return y
 
         def conv_transpose1d(x, wp, cout, stride, pad, **kw):
@@ -84,7 +84,7 @@ class KernelEvents:
             e0.record()
             y = orig_tr(x, wp, cout, stride, pad, **kw)
             e1.record()
-            rec.append((ops.conv_kernel_name(cin, cout, 2 * stride, stride, 1, transposed=True, tin=tin),
+            rec.append((ops.conv_kernel_name(cin, cout, 2 * stride, stride, 1, transposed=True, tin=tin, batch=B),
                         2.0 * cin * cout * 2 * stride * tin * B, e0, e1))
             return y
 

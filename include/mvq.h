@@ -72,10 +72,11 @@ int mvq_conv1d_f32(const float* x, const float* wp, const float* bias, const flo
                    void* stream);
 
 /* Name of the kernel instantiation the two conv entry points launch for a shape ("conv1d_mfma_kernel<...>" as
- * rocprofv3 prints it, or "conv1d_direct_kernel"): lets bench.py match its HIP-event timings to the trace.
- * For transposed convs pass the torch shape (cin, cout, ks = 2*stride, stride).  tin = input length (tile shape
- * depends on it for the latent-rate layers; "same"/DAC padding is assumed). */
-int mvq_conv_kernel_name(int cin, int cout, int ks, int stride, int dil, int transposed, int tin, char* buf, int len);
+ * rocprofv3 prints it, or "conv1d_direct_kernel"): lets bench.py match its HIP-event timings to the trace.  Tile shape
+ * depends on batch and length (64 x 64 tiles in the latency regime, 128 x 96 at the latent rate); "same"/DAC padding is
+ * assumed.  For transposed convs pass the torch shape (cin, cout, ks = 2*stride, stride). */
+int mvq_conv_kernel_name(int batch, int cin, int cout, int ks, int stride, int dil, int transposed, int tin,
+                         char* buf, int len);
 
 /* One upstream dac ResidualUnit:  y = snake_next?( x + conv1( snake_b( conv7_dil( snake_a(x) ) + b7 ) ) + b1 ),
  * 7-tap conv with dilation `dil` and padding 3*dil, then a 1x1 conv, both C -> C.  For C in {64, 96, 128} (the

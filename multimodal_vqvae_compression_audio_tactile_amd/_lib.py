@@ -24,7 +24,7 @@ EXPORTS = {
     "mvq_conv1d_pack_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mvq_conv_transpose1d_packed_floats": (c_size_t, [c_int, c_int, c_int]),
     "mvq_conv_transpose1d_pack_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "mvq_conv_kernel_name": (c_int, [c_int] * 7 + [c_char_p, c_int]),
+    "mvq_conv_kernel_name": (c_int, [c_int] * 8 + [c_char_p, c_int]),
     "mvq_conv1d_f32": (c_int, [c_void_p] * 7 + [c_int] * 9 + [c_void_p]),
     "mvq_residual_unit_scratch_floats": (c_size_t, [c_int] * 4),
     "mvq_residual_unit_kernel_name": (c_int, [c_int, c_int, c_char_p, c_int]),

@@ -79,29 +79,44 @@ int mvq_conv_transpose1d_pack_f32(const float* w, float* wp, int cin, int cout, 
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv_transpose1d_pack");
 }
 
-/* which kernel instantiation mvq_conv1d_f32 / mvq_conv_transpose1d_f32 launches for a shape (profiling aid) */
-int mvq_conv_kernel_name(int cin, int cout, int ks, int stride, int dil, int transposed, int tin, char* buf, int len)
+static hipError_t dispatch_conv1d(const mvq::ConvArgs& a, int ks, int stride, int dil, hipStream_t s)
+{
+    const int bm = mvq::conv_tile_bm(a.Cout);
+    hipError_t e = hipErrorInvalidValue;
+    if (a.Cout >= 32 && a.Cin >= 32) {                 // a dense (channels x kernel) tile exists
+        if (ks == 7 && stride == 1 && a.Cin % 8 == 0) e = mvq::launch_conv_k7(a, dil, bm, s);
+        else if (ks == 1 && stride == 1 && dil == 1 && a.Cin % 32 == 0) e = mvq::launch_conv_k1k3(a, 1, bm, s);
+        else if (ks == 3 && stride == 1 && dil == 1 && a.Cin % 16 == 0) e = mvq::launch_conv_k1k3(a, 3, bm, s);
+        else if (ks == 2 * stride && dil == 1 && a.Cin % 16 == 0) e = mvq::launch_conv_strided(a, stride, bm, s);
+    }
+    return e;
+}
+
+static hipError_t dispatch_convtr(const mvq::ConvArgs& a, hipStream_t s)
+{
+    if (a.Cin % 32 != 0 || a.Mrows < 64) return hipErrorInvalidValue;
+    return mvq::launch_conv_tr(a, mvq::conv_tile_bm(a.Mrows), s);
+}
+
+/* which kernel instantiation mvq_conv1d_f32 / mvq_conv_transpose1d_f32 launches for a shape (profiling aid):
+ * runs the real dispatch in "name mode" */
+int mvq_conv_kernel_name(int batch, int cin, int cout, int ks, int stride, int dil, int transposed, int tin, char* buf, int len)
 {
     if (!buf || len <= 0) return fail(MVQ_EINVAL, "conv_kernel_name: bad buffer");
-    const int mrows = transposed ? cout * stride : cout;
-    const int bm = mvq::conv_tile_bm(mrows);
-    const int ncols = transposed ? tin + 1 : conv_out_len(tin, ks, stride, dil, transposed ? 0 : (stride == 1 ? (ks - 1) * dil / 2 : (stride + 1) / 2));
-    const bool narrow = bm == 128 && ncols > 0 && ncols <= 96 &&
-                        (transposed || (ks == 7 && dil == 1 && stride == 1) || ks == 3 || (ks == 16 && stride == 8));
-    const char* tile = narrow ? "1, 3, 4, 1" : (bm == 128 ? "2, 2, 2, 2" : (bm == 96 ? "3, 1, 1, 4" : "2, 2, 1, 4"));
-    int K = 0, S = 1, D = 1, CK = 0;
+    mvq::ConvArgs a{};
+    a.B = batch; a.Cin = cin; a.Tin = tin; a.Cout = cout; a.name_out = buf; a.name_len = len;
+    hipError_t e;
     if (transposed) {
-        if (cin % 32 == 0 && ((bm == 128 && (stride == 8 || stride == 5 || stride == 4 || stride == 2)) || (bm == 96 && stride == 2))) { K = 2; CK = 32; }
-    } else if (cout >= 32 && cin >= 32) {
-        if (ks == 7 && stride == 1 && cin % 8 == 0 && (dil == 1 || dil == 3 || dil == 9)) { K = 7; D = dil; CK = 8; }
-        else if (ks == 1 && stride == 1 && dil == 1 && cin % 32 == 0) { K = 1; CK = 32; }
-        else if (ks == 3 && stride == 1 && dil == 1 && cin % 16 == 0 && bm == 128) { K = 3; CK = 16; }
-        else if (ks == 2 * stride && dil == 1 && cin % 16 == 0 && bm == 128 && (stride == 2 || stride == 4 || stride == 5 || stride == 8)) {
-            K = ks; S = stride; CK = stride == 2 ? 16 : (stride == 4 ? 8 : 4);
-        }
+        a.Mrows = cout * stride; a.Mpad = mvq::conv_mpad(a.Mrows); a.Ncols = tin + 1; a.up_s = stride; a.pad = 1;
+        e = dispatch_convtr(a, nullptr);
+        if (e != hipSuccess) snprintf(buf, len, "convtr_direct_kernel");
+    } else {
+        const int pad = stride == 1 ? (ks - 1) * dil / 2 : (stride + 1) / 2;
+        a.Mrows = cout; a.Mpad = mvq::conv_mpad(cout); a.Ncols = conv_out_len(tin, ks, stride, dil, pad); a.pad = pad;
+        a.Tout = a.Ncols; a.up_s = 1;
+        e = dispatch_conv1d(a, ks, stride, dil, nullptr);
+        if (e != hipSuccess) snprintf(buf, len, "conv1d_direct_kernel");
     }
-    if (K == 0) snprintf(buf, len, "%s", transposed ? "convtr_direct_kernel" : "conv1d_direct_kernel");
-    else snprintf(buf, len, "conv1d_mfma_kernel<%d, %d, %d, %d, %s, %d>", K, S, D, CK, tile, transposed ? stride : 0);
     return MVQ_OK;
 }
 
@@ -116,21 +131,13 @@ int mvq_conv1d_f32(const float* x, const float* wp, const float* bias, const flo
     if (batch == 0 || tout == 0) return MVQ_OK;
     if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv1d: null tensor");
     const int mpad = mvq::conv_mpad(cout);
-    const int bm = mvq::conv_tile_bm(cout);
 
     mvq::ConvArgs a{};
     a.x = x; a.wp = wp; a.bias = bias; a.alpha_in = alpha_in; a.residual = residual; a.alpha_out = alpha_out; a.y = y;
     a.B = batch; a.Cin = cin; a.Tin = tin; a.Cout = cout; a.Tout = tout; a.pad = pad; a.Mpad = mpad;
     a.Mrows = cout; a.Ncols = tout; a.act = act; a.up_s = 1; a.up_p = 0;
 
-    hipError_t e = hipErrorInvalidValue;
-    const bool dense = cout >= 32 && cin >= 32;      // a dense (channels x kernel) tile exists
-    if (dense) {
-        if (ks == 7 && stride == 1 && cin % 8 == 0) e = mvq::launch_conv_k7(a, dil, bm, S(stream));
-        else if (ks == 1 && stride == 1 && dil == 1 && cin % 32 == 0) e = mvq::launch_conv_k1k3(a, 1, bm, S(stream));
-        else if (ks == 3 && stride == 1 && dil == 1 && cin % 16 == 0) e = mvq::launch_conv_k1k3(a, 3, bm, S(stream));
-        else if (ks == 2 * stride && dil == 1 && cin % 16 == 0) e = mvq::launch_conv_strided(a, stride, bm, S(stream));
-    }
+    hipError_t e = dispatch_conv1d(a, ks, stride, dil, S(stream));
     if (e == hipErrorInvalidValue) {
         (void)hipGetLastError();
         mvq::DirectConvArgs d{x, wp, bias, alpha_in, residual, alpha_out, y, batch, cin, tin, cout, tout, ks, stride, dil, pad, mpad, act};
@@ -148,8 +155,9 @@ int mvq_residual_unit_kernel_name(int c, int dil, char* buf, int len)
 {
     if (!buf || len <= 0) return fail(MVQ_EINVAL, "residual_unit_kernel_name: bad buffer");
     if (!ru_fusable(c, dil)) { snprintf(buf, len, "%s", "(two launches)"); return MVQ_OK; }
-    const char* tile = c == 128 ? "2, 2, 2, 2" : (c == 96 ? "3, 1, 1, 4" : "2, 2, 1, 4");
-    snprintf(buf, len, "residual_unit_kernel<%d, 8, %s>", dil, tile);
+    mvq::ConvArgs a{};
+    a.Cin = c; a.Cout = c; a.Mpad = mvq::conv_mpad(c); a.name_out = buf; a.name_len = len;
+    (void)mvq::launch_residual_unit_fused(a, dil, nullptr);
     return MVQ_OK;
 }
 
@@ -192,14 +200,13 @@ int mvq_conv_transpose1d_f32(const float* x, const float* wp, const float* bias,
     if (batch == 0 || tin == 0 || tout <= 0) return MVQ_OK;
     const int mrows = cout * stride;
     const int mpad = mvq::conv_mpad(mrows);
-    const int bm = mvq::conv_tile_bm(mrows);
-    hipError_t e = hipErrorInvalidValue;
-    if (cin % 32 == 0 && mrows >= 64) {
+    hipError_t e;
+    {
         mvq::ConvArgs a{};
         a.x = x; a.wp = wp; a.bias = bias; a.alpha_in = alpha_in; a.residual = nullptr; a.alpha_out = alpha_out; a.y = y;
         a.B = batch; a.Cin = cin; a.Tin = tin; a.Cout = cout; a.Tout = tout; a.pad = 1; a.Mpad = mpad;
         a.Mrows = mrows; a.Ncols = tin + 1; a.act = 0; a.up_s = stride; a.up_p = pad;
-        e = mvq::launch_conv_tr(a, bm, S(stream));
+        e = dispatch_convtr(a, S(stream));
     }
     if (e == hipErrorInvalidValue) {
         (void)hipGetLastError();

@@ -19,6 +19,7 @@
 // M = Cout*S rows whose row (co*S + r) is written to y[co, q*S + r - P].
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include "det_math.hpp"
 
 namespace mvq {
@@ -48,6 +49,8 @@ struct ConvArgs {
     const float* alpha_mid; // [C] Snake between the two convs
     const float* w2p;       // packed 1x1 weights [(c) * Mpad + co]
     const float* bias2;     // [C] or null
+    char* name_out;         // host only: when set, launchers write the kernel instantiation name here and do not launch
+    int name_len;
 };
 
 template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, int UPS>
@@ -498,6 +501,10 @@ inline hipError_t launch_residual_unit(const ConvArgs& a_in, hipStream_t stream)
     using C = ConvCfg<7, 1, DIL, CK, MT, NT, WAVES_M, WAVES_N, 0>;
     ConvArgs a = a_in;
     if (a.Cin % CK != 0 || a.Cout != C::BM || a.Cin != C::BM || a.Mpad != C::BM) return hipErrorInvalidValue;
+    if (a.name_out) {
+        snprintf(a.name_out, a.name_len, "residual_unit_kernel<%d, %d, %d, %d, %d, %d>", DIL, CK, MT, NT, WAVES_M, WAVES_N);
+        return hipSuccess;
+    }
     a.n_tiles = (a.Ncols + C::BN - 1) / C::BN;
     a.vec4 = (a.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     a.ovec4 = (a.Tout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
@@ -521,7 +528,12 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
 {
     using C = ConvCfg<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS>;
     ConvArgs a = a_in;
-    if (a.Cin % CK != 0) return hipErrorInvalidValue;
+    if (a.Cin % CK != 0 || a.Mpad % C::BM != 0) return hipErrorInvalidValue;
+    if (a.name_out) {
+        snprintf(a.name_out, a.name_len, "conv1d_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", KS, STRIDE, DIL, CK, MT, NT,
+                 WAVES_M, WAVES_N, UPS);
+        return hipSuccess;
+    }
     a.n_tiles = (a.Ncols + C::BN - 1) / C::BN;
     a.vec4 = (a.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     a.ovec4 = (a.Tout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
@@ -550,5 +562,14 @@ inline int conv_tile_bm(int mrows)
     return mrows > 96 ? 128 : (mrows > 64 ? 96 : 64);
 }
 inline int conv_mpad(int mrows) { const int bm = conv_tile_bm(mrows); return (mrows + bm - 1) / bm * bm; }
+
+// Latency regime: when the 128-row tiling would leave most of the 256 CUs idle (small batch x short sequences), the
+// same kernel runs with 64 x 64 tiles -- 4x the blocks, each walking the same K chain, so results are unchanged.
+inline bool conv_prefer_small_tiles(const ConvArgs& a)
+{
+    if (a.Mpad % 64 != 0) return false;
+    const long big = (long)a.B * ((a.Ncols + 127) / 128) * ((a.Mrows + 127) / 128);
+    return big < 160;
+}
 
 }  // namespace mvq

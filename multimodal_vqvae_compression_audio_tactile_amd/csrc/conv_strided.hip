@@ -4,6 +4,14 @@ namespace mvq {
 hipError_t launch_conv_strided(const ConvArgs& a, int stride, int bm, hipStream_t s)
 {
     if (bm != 128) return hipErrorInvalidValue;
+    if (conv_prefer_small_tiles(a)) {
+        switch (stride) {
+            case 2: return launch_conv1d_mfma<4, 2, 1, 16, 1, 1, 2, 2, 0>(a, s);
+            case 4: return launch_conv1d_mfma<8, 4, 1, 8, 1, 1, 2, 2, 0>(a, s);
+            case 5: return launch_conv1d_mfma<10, 5, 1, 4, 1, 1, 2, 2, 0>(a, s);
+            case 8: return launch_conv1d_mfma<16, 8, 1, 4, 1, 1, 2, 2, 0>(a, s);
+        }
+    }
     switch (stride) {
         case 2: return launch_conv1d_mfma<4, 2, 1, 16, 2, 2, 2, 2, 0>(a, s);
         case 4: return launch_conv1d_mfma<8, 4, 1, 8, 2, 2, 2, 2, 0>(a, s);

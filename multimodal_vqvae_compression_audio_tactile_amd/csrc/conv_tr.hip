@@ -4,6 +4,14 @@
 namespace mvq {
 hipError_t launch_conv_tr(const ConvArgs& a, int bm, hipStream_t s)
 {
+    if (bm == 128 && conv_prefer_small_tiles(a)) {
+        switch (a.up_s) {
+            case 8: return launch_conv1d_mfma<2, 1, 1, 32, 1, 1, 2, 2, 8>(a, s);
+            case 5: return launch_conv1d_mfma<2, 1, 1, 32, 1, 1, 2, 2, 5>(a, s);
+            case 4: return launch_conv1d_mfma<2, 1, 1, 32, 1, 1, 2, 2, 4>(a, s);
+            case 2: return launch_conv1d_mfma<2, 1, 1, 32, 1, 1, 2, 2, 2>(a, s);
+        }
+    }
     const bool narrow = bm == 128 && a.Ncols <= 96;
     switch (a.up_s) {
         case 8: if (bm == 128) return narrow ? launch_conv1d_mfma<2, 1, 1, 32, 1, 3, 4, 1, 8>(a, s)

@@ -36,11 +36,11 @@ def conv1d_out_len(tin, ks, stride=1, dil=1, pad=0):
     return 0 if span < 0 else span // stride + 1
 
 
-def conv_kernel_name(cin, cout, ks, stride=1, dil=1, transposed=False, tin=24000) -> str:
+def conv_kernel_name(cin, cout, ks, stride=1, dil=1, transposed=False, tin=24000, batch=64) -> str:
     """Kernel instantiation the library launches for this conv shape (as rocprofv3 names it)."""
     import ctypes
     buf = ctypes.create_string_buffer(160)
-    check(_lib.lib().mvq_conv_kernel_name(cin, cout, ks, stride, dil, int(transposed), tin, buf, 160),
+    check(_lib.lib().mvq_conv_kernel_name(batch, cin, cout, ks, stride, dil, int(transposed), tin, buf, 160),
           "mvq_conv_kernel_name")
     return buf.value.decode()
 

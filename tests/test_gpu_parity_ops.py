@@ -42,6 +42,13 @@ CONV_CASES = [
     (1, 40, 100, 24, 5, 2, 2, 3, True, False, True, False),      # odd shape -> direct fallback
     (2, 1024, 75, 1536, 7, 1, 1, 3, False, False, True, False),  # decoder input conv: narrow 128x96 tile
     (2, 512, 600, 1024, 16, 8, 1, 4, False, False, True, False), # last encoder down-sampling conv (Tout = 75)
+    # latency regime (B = 1, short T): 64 x 64 tiles
+    (1, 512, 600, 512, 7, 1, 3, 9, True, False, True, False),
+    (1, 768, 600, 768, 1, 1, 1, 0, False, True, False, False),
+    (1, 1024, 16, 2048, 1, 1, 1, 0, False, False, False, False),
+    (1, 256, 3000, 512, 10, 5, 1, 3, False, False, True, False),
+    (1, 128, 1200, 256, 8, 4, 1, 2, False, False, False, False),
+    (1, 64, 800, 128, 4, 2, 1, 1, False, False, False, False),
 ]
 
 
@@ -78,6 +85,8 @@ CONVTR_CASES = [
     (1, 48, 33, 20, 3, True, False),     # direct fallback
     (2, 1536, 75, 768, 8, False, False), # dec.b0 up-sampling at the latent rate (narrow tile), pre-snaked input
     (1, 256, 40, 128, 2, True, True),    # stride 2 with a 128-row tile
+    (1, 768, 600, 384, 5, False, True),  # latency regime: 64-row tile, 5 phases (direct store)
+    (1, 384, 299, 192, 4, True, False),  # latency regime: 64-row tile, pixel-shuffle through LDS
 ]
 
 

@@ -58,7 +58,7 @@ for (name, kind, cin, cout, ks, st, dil, tin, ai, res, ao, count) in layers:
         wp = ops.pack_conv_transpose1d(w, st)
         f = lambda: ops.conv_transpose1d(x, wp, cout, st, math.ceil(st / 2))
         flops = 2.0 * cin * cout * ks * Tx * Bx
-        kname = ops.conv_kernel_name(cin, cout, ks, st, 1, True, tin=Tx)
+        kname = ops.conv_kernel_name(cin, cout, ks, st, 1, True, tin=Tx, batch=Bx)
     else:
         w = torch.randn(cout, cin, ks, device=dev) / math.sqrt(cin * ks)
         wp = ops.pack_conv1d(w)
@@ -70,7 +70,7 @@ for (name, kind, cin, cout, ks, st, dil, tin, ai, res, ao, count) in layers:
         bias = torch.randn(cout, device=dev)
         f = lambda: ops.conv1d(x, wp, cout, ks, bias=bias, stride=st, dil=dil, pad=pad, alpha_in=a_in, residual=r, alpha_out=a_out)
         flops = 2.0 * cin * cout * ks * tout * Bx
-        kname = ops.conv_kernel_name(cin, cout, ks, st, dil, tin=Tx)
+        kname = ops.conv_kernel_name(cin, cout, ks, st, dil, tin=Tx, batch=Bx)
     f(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     n = 5
