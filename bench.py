@@ -59,11 +59,11 @@ class KernelEvents:
         orig_conv, orig_tr, orig_ru = ops.conv1d, ops.conv_transpose1d, ops.residual_unit_fused
         rec = self.records
 
-        def residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None):
+        def residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, alpha_dual=None):
             B, c, t = x.shape
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            y = orig_ru(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next)
+            y = orig_ru(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next, alpha_dual)
             e1.record()
             rec.append((ops.residual_unit_kernel_name(c, dil), 2.0 * c * c * 8 * t * B, e0, e1))
             return y

@@ -71,6 +71,18 @@ int mvq_conv1d_f32(const float* x, const float* wp, const float* bias, const flo
                    int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act,
                    void* stream);
 
+/* Dual-output forms.  Besides y they write  y2 = snake(v, alpha2)  where v is the value before alpha_out / act
+ * (conv + bias + residual): the Snake1d that the NEXT ResidualUnit applies to its input, hoisted into the producer so
+ * that a consumer with M/128 row tiles does not re-evaluate it M/128 times per element while staging.  y2[B,Cout,Tout],
+ * alpha2[Cout]; pass both or neither (NULL, NULL == the plain entry points above / below). */
+int mvq_conv1d_dual_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                        const float* residual, const float* alpha_out, float* y, float* y2, const float* alpha2,
+                        int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act,
+                        void* stream);
+int mvq_conv_transpose1d_dual_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                                  const float* alpha_out, float* y, float* y2, const float* alpha2,
+                                  int batch, int cin, int tin, int cout, int stride, int pad, void* stream);
+
 /* Name of the kernel instantiation the two conv entry points launch for a shape ("conv1d_mfma_kernel<...>" as
  * rocprofv3 prints it, or "conv1d_direct_kernel"): lets bench.py match its HIP-event timings to the trace.  Tile shape
  * depends on batch and length (64 x 64 tiles in the latency regime, 128 x 96 at the latent rate); "same"/DAC padding is
@@ -88,6 +100,13 @@ int mvq_residual_unit_kernel_name(int c, int dil, char* buf, int len);   /* "res
 int mvq_residual_unit_f32(const float* x, const float* w7p, const float* b7, const float* alpha_a,
                           const float* alpha_b, const float* w1p, const float* b1, const float* alpha_next,
                           float* y, float* scratch, int batch, int c, int t, int dil, void* stream);
+
+/* ResidualUnit with a pre-snaked input and/or dual output: x_snaked = snake_a(x) (from a producer's y2) or NULL;
+ * y2 = snake(y_raw, alpha2) for the next unit or NULL. */
+int mvq_residual_unit_dual_f32(const float* x, const float* x_snaked, const float* w7p, const float* b7,
+                               const float* alpha_a, const float* alpha_b, const float* w1p, const float* b1,
+                               const float* alpha_next, float* y, float* y2, const float* alpha2, float* scratch,
+                               int batch, int c, int t, int dil, void* stream);
 
 /* y = snake_out( conv_transpose1d( snake_in(x) ) + bias ), kernel = 2*stride, torch `padding` = pad.
  * Replaces the Snake1d + WNConvTranspose1d at the head of every upstream DecoderBlock.

@@ -29,6 +29,9 @@ EXPORTS = {
     "mvq_residual_unit_scratch_floats": (c_size_t, [c_int] * 4),
     "mvq_residual_unit_kernel_name": (c_int, [c_int, c_int, c_char_p, c_int]),
     "mvq_residual_unit_f32": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p]),
+    "mvq_conv1d_dual_f32": (c_int, [c_void_p] * 9 + [c_int] * 9 + [c_void_p]),
+    "mvq_conv_transpose1d_dual_f32": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
+    "mvq_residual_unit_dual_f32": (c_int, [c_void_p] * 13 + [c_int] * 4 + [c_void_p]),
     "mvq_conv_transpose1d_f32": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
     "mvq_rvq_ema_forward_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "mvq_rvq_ema_step_scratch_bytes": (c_size_t, [c_int] * 5),

@@ -120,10 +120,23 @@ int mvq_conv_kernel_name(int batch, int cin, int cout, int ks, int stride, int d
     return MVQ_OK;
 }
 
+int mvq_conv1d_dual_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                        const float* residual, const float* alpha_out, float* y, float* y2, const float* alpha2,
+                        int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act, void* stream);
+
 int mvq_conv1d_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
                    const float* residual, const float* alpha_out, float* y,
                    int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act, void* stream)
 {
+    return mvq_conv1d_dual_f32(x, wp, bias, alpha_in, residual, alpha_out, y, nullptr, nullptr,
+                               batch, cin, tin, cout, ks, stride, dil, pad, act, stream);
+}
+
+int mvq_conv1d_dual_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                        const float* residual, const float* alpha_out, float* y, float* y2, const float* alpha2,
+                        int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act, void* stream)
+{
+    if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "conv1d: y2 and alpha2 go together");
     if (batch < 0 || cin <= 0 || cout <= 0 || tin < 0 || ks <= 0 || stride <= 0 || dil <= 0 || pad < 0)
         return fail(MVQ_EINVAL, "conv1d: bad shape B=%d Cin=%d Tin=%d Cout=%d ks=%d s=%d d=%d p=%d", batch, cin, tin, cout, ks, stride, dil, pad);
     if (act != MVQ_ACT_NONE && act != MVQ_ACT_TANH) return fail(MVQ_EINVAL, "conv1d: bad act %d", act);
@@ -135,12 +148,12 @@ int mvq_conv1d_f32(const float* x, const float* wp, const float* bias, const flo
     mvq::ConvArgs a{};
     a.x = x; a.wp = wp; a.bias = bias; a.alpha_in = alpha_in; a.residual = residual; a.alpha_out = alpha_out; a.y = y;
     a.B = batch; a.Cin = cin; a.Tin = tin; a.Cout = cout; a.Tout = tout; a.pad = pad; a.Mpad = mpad;
-    a.Mrows = cout; a.Ncols = tout; a.act = act; a.up_s = 1; a.up_p = 0;
+    a.Mrows = cout; a.Ncols = tout; a.act = act; a.up_s = 1; a.up_p = 0; a.y2 = y2; a.alpha2 = alpha2;
 
     hipError_t e = dispatch_conv1d(a, ks, stride, dil, S(stream));
     if (e == hipErrorInvalidValue) {
         (void)hipGetLastError();
-        mvq::DirectConvArgs d{x, wp, bias, alpha_in, residual, alpha_out, y, batch, cin, tin, cout, tout, ks, stride, dil, pad, mpad, act};
+        mvq::DirectConvArgs d{x, wp, bias, alpha_in, residual, alpha_out, y, batch, cin, tin, cout, tout, ks, stride, dil, pad, mpad, act, y2, alpha2};
         e = mvq::launch_conv1d_direct(d, S(stream));
     }
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d");
@@ -167,32 +180,61 @@ size_t mvq_residual_unit_scratch_floats(int batch, int c, int t, int dil)
     return ru_fusable(c, dil) ? 0 : (size_t)batch * c * t;
 }
 
+int mvq_residual_unit_dual_f32(const float* x, const float* x_snaked, const float* w7p, const float* b7,
+                               const float* alpha_a, const float* alpha_b, const float* w1p, const float* b1,
+                               const float* alpha_next, float* y, float* y2, const float* alpha2, float* scratch,
+                               int batch, int c, int t, int dil, void* stream);
+
 int mvq_residual_unit_f32(const float* x, const float* w7p, const float* b7, const float* alpha_a,
                           const float* alpha_b, const float* w1p, const float* b1, const float* alpha_next,
                           float* y, float* scratch, int batch, int c, int t, int dil, void* stream)
 {
+    return mvq_residual_unit_dual_f32(x, nullptr, w7p, b7, alpha_a, alpha_b, w1p, b1, alpha_next, y, nullptr, nullptr,
+                                      scratch, batch, c, t, dil, stream);
+}
+
+int mvq_residual_unit_dual_f32(const float* x, const float* x_snaked, const float* w7p, const float* b7,
+                               const float* alpha_a, const float* alpha_b, const float* w1p, const float* b1,
+                               const float* alpha_next, float* y, float* y2, const float* alpha2, float* scratch,
+                               int batch, int c, int t, int dil, void* stream)
+{
     if (batch < 0 || c <= 0 || t < 0 || dil <= 0) return fail(MVQ_EINVAL, "residual_unit: bad shape");
     if (batch == 0 || t == 0) return MVQ_OK;
     if (!x || !w7p || !w1p || !alpha_a || !alpha_b || !y) return fail(MVQ_EINVAL, "residual_unit: null tensor");
+    if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "residual_unit: y2 and alpha2 go together");
     if (ru_fusable(c, dil)) {
         mvq::ConvArgs a{};
         a.x = x; a.wp = w7p; a.bias = b7; a.alpha_in = alpha_a; a.residual = x; a.alpha_out = alpha_next; a.y = y;
         a.B = batch; a.Cin = c; a.Tin = t; a.Cout = c; a.Tout = t; a.pad = 3 * dil; a.Mpad = mvq::conv_mpad(c);
         a.Mrows = c; a.Ncols = t; a.act = 0; a.up_s = 1; a.up_p = 0;
-        a.alpha_mid = alpha_b; a.w2p = w1p; a.bias2 = b1;
+        a.alpha_mid = alpha_b; a.w2p = w1p; a.bias2 = b1; a.y2 = y2; a.alpha2 = alpha2;
         hipError_t e = mvq::launch_residual_unit_fused(a, dil, S(stream));
         return e == hipSuccess ? MVQ_OK : hipfail(e, "residual_unit(fused)");
     }
     if (!scratch) return fail(MVQ_EINVAL, "residual_unit: scratch required for C=%d (see mvq_residual_unit_scratch_floats)", c);
-    int rc = mvq_conv1d_f32(x, w7p, b7, alpha_a, nullptr, alpha_b, scratch, batch, c, t, c, 7, 1, dil, 3 * dil, MVQ_ACT_NONE, stream);
+    int rc = x_snaked
+        ? mvq_conv1d_f32(x_snaked, w7p, b7, nullptr, nullptr, alpha_b, scratch, batch, c, t, c, 7, 1, dil, 3 * dil, MVQ_ACT_NONE, stream)
+        : mvq_conv1d_f32(x, w7p, b7, alpha_a, nullptr, alpha_b, scratch, batch, c, t, c, 7, 1, dil, 3 * dil, MVQ_ACT_NONE, stream);
     if (rc != MVQ_OK) return rc;
-    return mvq_conv1d_f32(scratch, w1p, b1, nullptr, x, alpha_next, y, batch, c, t, c, 1, 1, 1, 0, MVQ_ACT_NONE, stream);
+    return mvq_conv1d_dual_f32(scratch, w1p, b1, nullptr, x, alpha_next, y, y2, alpha2, batch, c, t, c, 1, 1, 1, 0, MVQ_ACT_NONE, stream);
 }
+
+int mvq_conv_transpose1d_dual_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                                  const float* alpha_out, float* y, float* y2, const float* alpha2,
+                                  int batch, int cin, int tin, int cout, int stride, int pad, void* stream);
 
 int mvq_conv_transpose1d_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
                              const float* alpha_out, float* y,
                              int batch, int cin, int tin, int cout, int stride, int pad, void* stream)
 {
+    return mvq_conv_transpose1d_dual_f32(x, wp, bias, alpha_in, alpha_out, y, nullptr, nullptr, batch, cin, tin, cout, stride, pad, stream);
+}
+
+int mvq_conv_transpose1d_dual_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                                  const float* alpha_out, float* y, float* y2, const float* alpha2,
+                                  int batch, int cin, int tin, int cout, int stride, int pad, void* stream)
+{
+    if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "conv_transpose1d: y2 and alpha2 go together");
     if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv_transpose1d: null tensor");
     if (batch < 0 || cin <= 0 || cout <= 0 || tin < 0 || stride <= 0 || pad < 0)
         return fail(MVQ_EINVAL, "conv_transpose1d: bad shape");
@@ -205,12 +247,12 @@ int mvq_conv_transpose1d_f32(const float* x, const float* wp, const float* bias,
         mvq::ConvArgs a{};
         a.x = x; a.wp = wp; a.bias = bias; a.alpha_in = alpha_in; a.residual = nullptr; a.alpha_out = alpha_out; a.y = y;
         a.B = batch; a.Cin = cin; a.Tin = tin; a.Cout = cout; a.Tout = tout; a.pad = 1; a.Mpad = mpad;
-        a.Mrows = mrows; a.Ncols = tin + 1; a.act = 0; a.up_s = stride; a.up_p = pad;
+        a.Mrows = mrows; a.Ncols = tin + 1; a.act = 0; a.up_s = stride; a.up_p = pad; a.y2 = y2; a.alpha2 = alpha2;
         e = dispatch_convtr(a, S(stream));
     }
     if (e == hipErrorInvalidValue) {
         (void)hipGetLastError();
-        mvq::DirectConvArgs d{x, wp, bias, alpha_in, nullptr, alpha_out, y, batch, cin, tin, cout, tout, 2 * stride, stride, 1, pad, mpad, 0};
+        mvq::DirectConvArgs d{x, wp, bias, alpha_in, nullptr, alpha_out, y, batch, cin, tin, cout, tout, 2 * stride, stride, 1, pad, mpad, 0, y2, alpha2};
         e = mvq::launch_convtr_direct(d, S(stream));
     }
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv_transpose1d");

@@ -49,6 +49,11 @@ struct ConvArgs {
     const float* alpha_mid; // [C] Snake between the two convs
     const float* w2p;       // packed 1x1 weights [(c) * Mpad + co]
     const float* bias2;     // [C] or null
+    // dual output: y2 = snake(v, alpha2) of the value BEFORE alpha_out/act, i.e. the Snake1d the next ResidualUnit
+    // applies to its input.  Hoists that Snake out of the consumer's staging loop (where a layer with M/BM row tiles
+    // would evaluate it M/BM times per element); the consumer then needs no alpha_in.
+    float* y2;
+    const float* alpha2;
     char* name_out;         // host only: when set, launchers write the kernel instantiation name here and do not launch
     int name_len;
 };
@@ -393,6 +398,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     const bool ok = mok && n < a.Ncols && t >= 0 && t < a.Tout;
                     t = ok ? t : 0;
                     float v = acc[i][j][r] + bv;
+                    if (ok && a.y2) { const float a2 = a.alpha2[co]; a.y2[rowoff + t] = det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
                     if (snake_out) v = det_snake(v, al, inv);
                     if (ok) a.y[rowoff + t] = v;
                 }
@@ -430,6 +436,11 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                         const f32x4 rv = *reinterpret_cast<const f32x4*>(a.residual + off);
                         v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
                     }
+                    if (a.y2) {
+                        const float a2 = a.alpha2[m], i2 = 1.0f / (a2 + 1e-9f);
+                        f32x4 w = {det_snake(v.x, a2, i2), det_snake(v.y, a2, i2), det_snake(v.z, a2, i2), det_snake(v.w, a2, i2)};
+                        *reinterpret_cast<f32x4*>(a.y2 + off) = w;
+                    }
                     if (snake_out) {
                         const float al = a.alpha_out[m], inv = 1.0f / (al + 1e-9f);
                         v.x = det_snake(v.x, al, inv); v.y = det_snake(v.y, al, inv);
@@ -450,6 +461,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     const size_t off = ((size_t)b * a.Cout + m) * a.Tout + n;
                     float v = Ct[row * C::BNP + col] + (ep_bias ? ep_bias[m] : 0.0f);
                     if (has_res) v = v + a.residual[off];
+                    if (a.y2) { const float a2 = a.alpha2[m]; a.y2[off] = det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
                     if (snake_out) { const float al = a.alpha_out[m]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
                     if (do_tanh) v = det_tanh(v);
                     a.y[off] = v;
@@ -471,8 +483,10 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             const int t = t_base + tl;
             if (co < a.Cout && n0 + nl < a.Ncols && t >= 0 && t < a.Tout) {
                 float v = Ct[(col * S + rr) * C::BNP + nl] + (ep_bias ? ep_bias[co] : 0.0f);
+                const size_t off = ((size_t)b * a.Cout + co) * a.Tout + t;
+                if (a.y2) { const float a2 = a.alpha2[co]; a.y2[off] = det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
                 if (snake_out) { const float al = a.alpha_out[co]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
-                a.y[((size_t)b * a.Cout + co) * a.Tout + t] = v;
+                a.y[off] = v;
             }
         }
     }
@@ -537,7 +551,8 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
     a.n_tiles = (a.Ncols + C::BN - 1) / C::BN;
     a.vec4 = (a.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     a.ovec4 = (a.Tout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
-              (!a.residual || (reinterpret_cast<uintptr_t>(a.residual) & 15) == 0);
+              (!a.residual || (reinterpret_cast<uintptr_t>(a.residual) & 15) == 0) &&
+              (!a.y2 || (reinterpret_cast<uintptr_t>(a.y2) & 15) == 0);
     const size_t lds = (size_t)C::LDS_FLOATS * 4 + (a.alpha_in ? (size_t)2 * a.Cin * 4 : 0);
     auto kern = conv1d_mfma_kernel<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS>;
     static bool attr_set = false;

@@ -109,6 +109,7 @@ __global__ void conv1d_direct_kernel(DirectConvArgs a)
         }
         float v = acc + (a.bias ? a.bias[co] : 0.0f);
         if (a.residual) v = v + a.residual[i];
+        if (a.y2) { const float a2 = a.alpha2[co]; a.y2[i] = det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
         if (a.alpha_out) { const float al = a.alpha_out[co]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
         if (a.act == 1) v = det_tanh(v);
         a.y[i] = v;
@@ -150,6 +151,7 @@ __global__ void convtr_direct_kernel(DirectConvArgs a)   // a.stride = S, a.pad 
             acc = dfma(a.wp[((size_t)ci * 2 + 1) * a.Mpad + m], x1, acc);
         }
         float v = acc + (a.bias ? a.bias[co] : 0.0f);
+        if (a.y2) { const float a2 = a.alpha2[co]; a.y2[i] = det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
         if (a.alpha_out) { const float al = a.alpha_out[co]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
         a.y[i] = v;
     }

@@ -10,6 +10,7 @@ struct DirectConvArgs {
     const float* x; const float* wp; const float* bias; const float* alpha_in; const float* residual;
     const float* alpha_out; float* y;
     int B, Cin, Tin, Cout, Tout, ks, stride, dil, pad, Mpad, act;
+    float* y2; const float* alpha2;       // dual output (see ConvArgs::y2)
 };
 
 hipError_t launch_weight_norm(const float* v, const float* g, float* w, int rows, int inner, hipStream_t s);

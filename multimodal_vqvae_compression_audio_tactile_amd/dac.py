@@ -76,10 +76,10 @@ class WNConv1d(nn.Module):
     def folded_weight(self) -> torch.Tensor:
         return ops.weight_norm(self.weight_v.detach(), self.weight_g.detach())
 
-    def run(self, x, alpha_in=None, residual=None, alpha_out=None, tanh=False):
+    def run(self, x, alpha_in=None, residual=None, alpha_out=None, tanh=False, alpha_dual=None):
         return ops.conv1d(x, self.packed(), self.cout, self.ks, bias=self.bias.detach(), stride=self.stride,
                           dil=self.dilation, pad=self.padding, alpha_in=alpha_in, residual=residual,
-                          alpha_out=alpha_out, tanh=tanh)
+                          alpha_out=alpha_out, tanh=tanh, alpha_dual=alpha_dual)
 
     def forward(self, x):
         return self.run(x)
@@ -104,9 +104,9 @@ class WNConvTranspose1d(nn.Module):
                                 lambda: ops.pack_conv_transpose1d(
                                     ops.weight_norm(self.weight_v.detach(), self.weight_g.detach()), self.stride))
 
-    def run(self, x, alpha_in=None, alpha_out=None):
+    def run(self, x, alpha_in=None, alpha_out=None, alpha_dual=None):
         return ops.conv_transpose1d(x, self.packed(), self.cout, self.stride, self.padding, bias=self.bias.detach(),
-                                    alpha_in=alpha_in, alpha_out=alpha_out)
+                                    alpha_in=alpha_in, alpha_out=alpha_out, alpha_dual=alpha_dual)
 
     def forward(self, x):
         return self.run(x)
@@ -123,10 +123,16 @@ class ResidualUnit(nn.Module):
         self.block = nn.Sequential(Snake1d(dim), WNConv1d(dim, dim, 7, dilation=dilation, padding=pad),
                                    Snake1d(dim), WNConv1d(dim, dim, 1))
 
-    def run(self, x, alpha_next=None):
+    # Wide units (C >= 192, several 128-row tiles per time tile) take their input Snake from the producer's dual output
+    # instead of re-evaluating it once per row tile while staging.
+    def wants_presnaked(self) -> bool:
+        return self.block[1].cin > 128
+
+    def run(self, x, alpha_next=None, x_snaked=None, alpha_dual=None):
         c7, c1 = self.block[1], self.block[3]
         return ops.residual_unit(x, c7.packed(), c7.bias.detach(), self.block[0].flat(), self.block[2].flat(),
-                                 c1.packed(), c1.bias.detach(), c7.dilation, alpha_next=alpha_next)
+                                 c1.packed(), c1.bias.detach(), c7.dilation, alpha_next=alpha_next, x_snaked=x_snaked,
+                                 alpha_dual=alpha_dual)
 
     def forward(self, x):
         return self.run(x)
@@ -139,11 +145,22 @@ class EncoderBlock(nn.Module):
                                    Snake1d(dim // 2),
                                    WNConv1d(dim // 2, dim, 2 * stride, stride=stride, padding=math.ceil(stride / 2)))
 
-    def run(self, x, alpha_next=None):
-        x = self.block[0].run(x)
-        x = self.block[1].run(x)
-        x = self.block[2].run(x, alpha_next=self.block[3].flat())     # Snake before the strided conv, fused
-        return self.block[4].run(x, alpha_out=alpha_next)
+    def run(self, x, alpha_next=None, x_snaked=None, alpha_dual=None):
+        r0, r1, r2 = self.block[0], self.block[1], self.block[2]
+        wide = r0.wants_presnaked()
+        if wide:
+            x, xs = r0.run(x, x_snaked=x_snaked, alpha_dual=r1.block[0].flat())
+            x, xs = r1.run(x, x_snaked=xs, alpha_dual=r2.block[0].flat())
+            x = r2.run(x, x_snaked=xs, alpha_next=self.block[3].flat())
+        else:
+            x = r0.run(x)
+            x = r1.run(x)
+            x = r2.run(x, alpha_next=self.block[3].flat())            # Snake before the strided conv, fused
+        return self.block[4].run(x, alpha_out=alpha_next, alpha_dual=alpha_dual)
+
+    def first_alpha(self):
+        """alpha of the first ResidualUnit's input Snake if that unit wants it pre-applied by the producer."""
+        return self.block[0].block[0].flat() if self.block[0].wants_presnaked() else None
 
     def forward(self, x):
         return self.run(x)
@@ -165,10 +182,12 @@ class Encoder(nn.Module):
     @torch.no_grad()
     def forward(self, x):
         n = len(self.block)
-        h = self.block[0].run(x)
+        h, hs = self.block[0].run(x), None
         for i in range(1, n - 2):
             last = i == n - 3
-            h = self.block[i].run(h, alpha_next=self.block[n - 2].flat() if last else None)
+            nxt = None if last else self.block[i + 1].first_alpha()   # next block's first unit wants a pre-snaked input?
+            out = self.block[i].run(h, alpha_next=self.block[n - 2].flat() if last else None, x_snaked=hs, alpha_dual=nxt)
+            h, hs = out if nxt is not None else (out, None)
         return self.block[n - 1].run(h)
 
 
@@ -181,10 +200,17 @@ class DecoderBlock(nn.Module):
 
     def run(self, x, alpha_next=None, pre_snaked=False):
         """`pre_snaked`: x already carries this block's leading Snake (fused into its producer's epilogue)."""
-        h = self.block[1].run(x, alpha_in=None if pre_snaked else self.block[0].flat())
-        h = self.block[2].run(h)
-        h = self.block[3].run(h)
-        return self.block[4].run(h, alpha_next=alpha_next)
+        r0, r1, r2 = self.block[2], self.block[3], self.block[4]
+        a_in = None if pre_snaked else self.block[0].flat()
+        if r0.wants_presnaked():
+            h, hs = self.block[1].run(x, alpha_in=a_in, alpha_dual=r0.block[0].flat())
+            h, hs = r0.run(h, x_snaked=hs, alpha_dual=r1.block[0].flat())
+            h, hs = r1.run(h, x_snaked=hs, alpha_dual=r2.block[0].flat())
+            return r2.run(h, x_snaked=hs, alpha_next=alpha_next)
+        h = self.block[1].run(x, alpha_in=a_in)
+        h = r0.run(h)
+        h = r1.run(h)
+        return r2.run(h, alpha_next=alpha_next)
 
     def forward(self, x):
         return self.run(x)

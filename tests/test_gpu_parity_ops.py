@@ -236,3 +236,46 @@ def test_residual_unit_bit_exact(case, orc, dev):
                             alpha_next=None if an is None else _t(an, dev))
     torch.cuda.synchronize()
     assert np.array_equal(got.cpu().numpy(), want), f"max abs diff {np.abs(got.cpu().numpy() - want).max()}"
+
+
+def test_dual_output_and_presnaked_input(orc, dev):
+    """y2 = snake(y_raw, alpha2) from conv / transposed-conv / residual-unit epilogues, and a residual unit fed with the
+    pre-snaked input, all equal to the plain composition."""
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    r = _rng(99)
+    for (B, Cin, Tin, Cout, ks, stride, pad) in [(2, 128, 600, 256, 8, 4, 2), (1, 64, 333, 64, 1, 1, 0), (2, 1, 500, 64, 7, 1, 3)]:
+        x = r.standard_normal((B, Cin, Tin)).astype(np.float32)
+        w = (r.standard_normal((Cout, Cin, ks)) / math.sqrt(Cin * ks)).astype(np.float32)
+        b = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+        a2 = r.uniform(0.5, 1.5, Cout).astype(np.float32)
+        want = orc.conv1d(x, w, b, stride, 1, pad)
+        y, y2 = ops.conv1d(_t(x, dev), ops.pack_conv1d(_t(w, dev)), Cout, ks, bias=_t(b, dev), stride=stride, pad=pad,
+                           alpha_dual=_t(a2, dev))
+        assert np.array_equal(y.cpu().numpy(), want)
+        assert np.array_equal(y2.cpu().numpy(), orc.snake(want, a2))
+    for (B, Cin, Tin, Cout, s) in [(1, 768, 77, 384, 5), (2, 384, 130, 192, 4), (1, 1536, 20, 768, 8)]:
+        pad = math.ceil(s / 2)
+        x = r.standard_normal((B, Cin, Tin)).astype(np.float32)
+        w = (r.standard_normal((Cin, Cout, 2 * s)) / math.sqrt(Cin * 2)).astype(np.float32)
+        b = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+        a2 = r.uniform(0.5, 1.5, Cout).astype(np.float32)
+        want = orc.conv_transpose1d(x, w, b, s, pad)
+        y, y2 = ops.conv_transpose1d(_t(x, dev), ops.pack_conv_transpose1d(_t(w, dev), s), Cout, s, pad, bias=_t(b, dev),
+                                     alpha_dual=_t(a2, dev))
+        assert np.array_equal(y.cpu().numpy(), want)
+        assert np.array_equal(y2.cpu().numpy(), orc.snake(want, a2))
+    for (B, C, T, dil) in [(1, 256, 300, 3), (2, 96, 400, 9)]:
+        x = r.standard_normal((B, C, T)).astype(np.float32)
+        w7 = (r.standard_normal((C, C, 7)) / math.sqrt(C * 7)).astype(np.float32)
+        w1 = (r.standard_normal((C, C, 1)) / math.sqrt(C)).astype(np.float32)
+        b7 = (0.1 * r.standard_normal(C)).astype(np.float32); b1 = (0.1 * r.standard_normal(C)).astype(np.float32)
+        aa, ab, a2 = (r.uniform(0.5, 1.5, C).astype(np.float32) for _ in range(3))
+        h = orc.conv1d(x, w7, b7, dil=dil, pad=3 * dil, alpha_in=aa)
+        want = orc.conv1d(h, w1, b1, alpha_in=ab, residual=x)
+        xs = ops.conv1d(_t(x, dev), ops.pack_conv1d(_t(np.eye(C, dtype=np.float32)[:, :, None], dev)), C, 1,
+                        alpha_dual=_t(aa, dev))[1]                       # snake_a(x) via an identity conv's dual output
+        assert np.array_equal(xs.cpu().numpy(), orc.snake(x, aa))
+        y, y2 = ops.residual_unit(_t(x, dev), ops.pack_conv1d(_t(w7, dev)), _t(b7, dev), _t(aa, dev), _t(ab, dev),
+                                  ops.pack_conv1d(_t(w1, dev)), _t(b1, dev), dil, x_snaked=xs, alpha_dual=_t(a2, dev))
+        assert np.array_equal(y.cpu().numpy(), want)
+        assert np.array_equal(y2.cpu().numpy(), orc.snake(want, a2))
