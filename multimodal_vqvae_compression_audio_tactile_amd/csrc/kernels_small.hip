@@ -116,8 +116,106 @@ __global__ void conv1d_direct_kernel(DirectConvArgs a)
     }
 }
 
+// Cin == 1, stride 1 (encoder input conv): one block row per (batch, output channel), 4 outputs per thread
+// (16-byte stores when rows are aligned), the KS taps + bias live in registers.
+template <int KS>
+__global__ __launch_bounds__(256) void conv1d_cin1_kernel(DirectConvArgs a)
+{
+    const int co = blockIdx.y, b = blockIdx.z;
+    const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t0 >= a.Tout) return;
+    float w[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) w[k] = a.wp[(size_t)k * a.Mpad + co];
+    const float bv = a.bias ? a.bias[co] : 0.0f;
+    const float* xr = a.x + (size_t)b * a.Tin;
+    float xv[KS + 3];
+#pragma unroll
+    for (int i = 0; i < KS + 3; ++i) {
+        const int g = t0 - a.pad + i * a.dil;            // dil == 1 for this kernel
+        xv[i] = (g >= 0 && g < a.Tin) ? xr[g] : 0.0f;
+    }
+    float al = 0.0f, inv = 0.0f, a2 = 0.0f, i2 = 0.0f;
+    if (a.alpha_out) { al = a.alpha_out[co]; inv = 1.0f / (al + 1e-9f); }
+    if (a.y2) { a2 = a.alpha2[co]; i2 = 1.0f / (a2 + 1e-9f); }
+    const size_t off = ((size_t)b * a.Cout + co) * a.Tout + t0;
+    float o[4], o2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) acc = dfma(w[k], xv[j + k], acc);
+        float v = acc + bv;
+        o2[j] = a.y2 ? det_snake(v, a2, i2) : 0.0f;
+        if (a.alpha_out) v = det_snake(v, al, inv);
+        if (a.act == 1) v = det_tanh(v);
+        o[j] = v;
+    }
+    const bool vec = (t0 + 3 < a.Tout) && ((off & 3) == 0);
+    if (vec) {
+        *reinterpret_cast<float4*>(a.y + off) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.y2) *reinterpret_cast<float4*>(a.y2 + off) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (t0 + j < a.Tout) { a.y[off + j] = o[j]; if (a.y2) a.y2[off + j] = o2[j]; }
+    }
+}
+
+// Cout == 1, stride 1, dil 1 (decoder output conv + tanh): 4 outputs per thread share a sliding window of KS+3
+// inputs per channel; weights staged in LDS.  Chain order per output: ci ascending, tap ascending (the contract).
+template <int KS>
+__global__ __launch_bounds__(256) void conv1d_cout1_kernel(DirectConvArgs a)
+{
+    extern __shared__ float wl[];                        // [Cin*KS]
+    for (int i = threadIdx.x; i < a.Cin * KS; i += 256) wl[i] = a.wp[(size_t)i * a.Mpad];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t0 >= a.Tout) return;
+    const float* xb = a.x + (size_t)b * a.Cin * a.Tin;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        const float* xr = xb + (size_t)ci * a.Tin;
+        float xv[KS + 3];
+#pragma unroll
+        for (int i = 0; i < KS + 3; ++i) {
+            const int g = t0 - a.pad + i;
+            xv[i] = (g >= 0 && g < a.Tin) ? xr[g] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const float w = wl[ci * KS + k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = dfma(w, xv[j + k], acc[j]);
+        }
+    }
+    const float bv = a.bias ? a.bias[0] : 0.0f;
+    const size_t off = (size_t)b * a.Tout + t0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (t0 + j < a.Tout) {
+            float v = acc[j] + bv;
+            if (a.residual) v = v + a.residual[off + j];
+            if (a.alpha_out) { const float al = a.alpha_out[0]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
+            if (a.act == 1) v = det_tanh(v);
+            a.y[off + j] = v;
+        }
+    }
+}
+
 hipError_t launch_conv1d_direct(const DirectConvArgs& a, hipStream_t s)
 {
+    if (a.Cin == 1 && a.ks == 7 && a.stride == 1 && a.dil == 1 && !a.alpha_in && !a.residual) {
+        dim3 grid((unsigned)((a.Tout + 1023) / 1024), (unsigned)a.Cout, (unsigned)a.B);
+        hipLaunchKernelGGL(conv1d_cin1_kernel<7>, grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+    if (a.Cout == 1 && a.ks == 7 && a.stride == 1 && a.dil == 1 && !a.alpha_in && !a.y2 && a.Cin * 7 * 4 <= 48 * 1024) {
+        dim3 grid((unsigned)((a.Tout + 1023) / 1024), (unsigned)a.B);
+        hipLaunchKernelGGL(conv1d_cout1_kernel<7>, grid, dim3(256), (size_t)a.Cin * 7 * sizeof(float), s, a);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)a.B * a.Cout * a.Tout;
     size_t blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
@@ -191,10 +289,20 @@ __global__ __launch_bounds__(256) void layernorm_c_tile_kernel(
     const int b = live ? n / T : 0, t = live ? n - b * T : 0;
     const float* xb = x + (size_t)b * sb + t;
     const float* per = pe ? pe + (size_t)t * C : nullptr;
-    for (int c = cg; c < C; c += 256 / LN_TOK) {
-        float v = 0.0f;
-        if (live) { v = xb[(size_t)c * sc]; if (per) v = v + per[c]; }
-        tile[c * LN_TOK + tok] = v;
+    constexpr int CG = 256 / LN_TOK;                                   // channel groups (8)
+    for (int c0 = cg; c0 < C; c0 += CG * 8) {                          // 8 loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * CG;
+            v[u] = (live && c < C) ? xb[(size_t)c * sc] : 0.0f;
+        }
+        if (per) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int c = c0 + u * CG; if (live && c < C) v[u] = v[u] + per[c]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int c = c0 + u * CG; if (c < C) tile[c * LN_TOK + tok] = v[u]; }
     }
     __syncthreads();
     if (tid < LN_TOK) {

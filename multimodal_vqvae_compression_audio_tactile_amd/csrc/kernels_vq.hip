@@ -52,10 +52,10 @@ __device__ __forceinline__ void copy_to_lds_f4(float* dst, const float* __restri
     }
 }
 
-constexpr int RVQ_TOKS = 8;      // tokens per block (2 per wave)
 constexpr int RVQ_KH = 256;      // codes resident in LDS at a time
 
 // LDS: Et[D][KH+1] | hn[KH] | resT[D][TOKS] | qsT[D][TOKS] | best_s[TOKS] | best_i[TOKS]
+template <int RVQ_TOKS>            // tokens per block: 8 (small batches: more blocks) or 32 (large: 4x less codebook staging)
 __global__ __launch_bounds__(256) void rvq_ema_forward_kernel(
     const float* __restrict__ z, const float* __restrict__ books, float* __restrict__ q_out,
     int32_t* __restrict__ idx_out, int B, int D, int T, int nb, int K, int update_residual)
@@ -119,9 +119,9 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_kernel(
                 hn[k] = 0.5f * s;
             }
             __syncthreads();
-            // each wave scores its 2 tokens against the resident codes (lane = code)
-            {
-                const int tok0 = wave * 2;
+            // each wave scores its tokens, 2 at a time, against the resident codes (lane = code)
+            for (int tp = 0; tp < RVQ_TOKS / 8; ++tp) {
+                const int tok0 = wave * (RVQ_TOKS / 4) + tp * 2;
                 float bs[2]; int bi[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) { bs[u] = -__builtin_inff(); bi[u] = 0x7fffffff; }
@@ -184,22 +184,30 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_kernel(
     }
 }
 
+template <int TOKS>
+static hipError_t launch_rvq_t(const float* z, const float* books, float* q_out, int32_t* idx_out,
+                               int B, int D, int T, int nb, int K, int update_residual, hipStream_t s)
+{
+    const int N = B * T;
+    const size_t lds = ((size_t)D * (RVQ_KH + 1) + RVQ_KH + 2 * (size_t)D * TOKS + 2 * TOKS) * sizeof(float);
+    auto kern = rvq_ema_forward_kernel<TOKS>;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((N + TOKS - 1) / TOKS), dim3(256), lds, s, z, books, q_out, idx_out, B, D, T, nb, K, update_residual);
+    return hipGetLastError();
+}
+
 hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_out, int32_t* idx_out,
                                   int B, int D, int T, int nb, int K, int update_residual, hipStream_t s)
 {
     const int N = B * T;
     if (N == 0) return hipSuccess;
-    const size_t lds = ((size_t)D * (RVQ_KH + 1) + RVQ_KH + 2 * (size_t)D * RVQ_TOKS + 2 * RVQ_TOKS) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_ema_forward_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
-    hipLaunchKernelGGL(rvq_ema_forward_kernel, dim3((N + RVQ_TOKS - 1) / RVQ_TOKS), dim3(256), lds, s,
-                       z, books, q_out, idx_out, B, D, T, nb, K, update_residual);
-    return hipGetLastError();
+    return N >= 4096 ? launch_rvq_t<32>(z, books, q_out, idx_out, B, D, T, nb, K, update_residual, s)
+                     : launch_rvq_t<8>(z, books, q_out, idx_out, B, D, T, nb, K, update_residual, s);
 }
 
 // ------------------------------------------------------------------------------------------------
