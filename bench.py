@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--workload", choices=["joint", "tactile"], default="joint")
     ap.add_argument("--books", type=int, default=8)
     ap.add_argument("--embed", type=int, default=512)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo for a "
+                    "single-GPU rehearsal of the multi-rank path together with MVQ_BENCH_ONE_DEVICE=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline = null)")
     return ap.parse_args()
@@ -147,13 +149,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP device); there is no CPU fallback for the product path")
+    if os.environ.get("MVQ_BENCH_ONE_DEVICE") == "1":     # rehearsal: every rank on cuda:0 (never on the 8-GPU node)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     import multimodal_vqvae_compression_audio_tactile_amd as mvq
     from multimodal_vqvae_compression_audio_tactile_amd import ops, synth
@@ -189,7 +197,7 @@ def main():
     if kev: kev._restore()
 
     if dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
