@@ -136,13 +136,14 @@ int mvq_conv1d_dual_f32(const float* x, const float* wp, const float* bias, cons
                         const float* residual, const float* alpha_out, float* y, float* y2, const float* alpha2,
                         int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act, void* stream)
 {
-    if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "conv1d: y2 and alpha2 go together");
+
     if (batch < 0 || cin <= 0 || cout <= 0 || tin < 0 || ks <= 0 || stride <= 0 || dil <= 0 || pad < 0)
         return fail(MVQ_EINVAL, "conv1d: bad shape B=%d Cin=%d Tin=%d Cout=%d ks=%d s=%d d=%d p=%d", batch, cin, tin, cout, ks, stride, dil, pad);
     if (act != MVQ_ACT_NONE && act != MVQ_ACT_TANH) return fail(MVQ_EINVAL, "conv1d: bad act %d", act);
     const int tout = conv_out_len(tin, ks, stride, dil, pad);
     if (batch == 0 || tout == 0) return MVQ_OK;
     if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv1d: null tensor");
+    if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "conv1d: y2 and alpha2 go together");
     const int mpad = mvq::conv_mpad(cout);
 
     mvq::ConvArgs a{};
@@ -234,12 +235,13 @@ int mvq_conv_transpose1d_dual_f32(const float* x, const float* wp, const float* 
                                   const float* alpha_out, float* y, float* y2, const float* alpha2,
                                   int batch, int cin, int tin, int cout, int stride, int pad, void* stream)
 {
-    if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "conv_transpose1d: y2 and alpha2 go together");
-    if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv_transpose1d: null tensor");
+
     if (batch < 0 || cin <= 0 || cout <= 0 || tin < 0 || stride <= 0 || pad < 0)
         return fail(MVQ_EINVAL, "conv_transpose1d: bad shape");
     const int tout = (tin - 1) * stride - 2 * pad + 2 * stride;
     if (batch == 0 || tin == 0 || tout <= 0) return MVQ_OK;
+    if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv_transpose1d: null tensor");
+    if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "conv_transpose1d: y2 and alpha2 go together");
     const int mrows = cout * stride;
     const int mpad = mvq::conv_mpad(mrows);
     hipError_t e;
@@ -278,9 +280,9 @@ size_t mvq_rvq_ema_step_scratch_bytes(int batch, int t, int nb, int k, int dim)
 int mvq_rvq_ema_step_f32(const float* z_tokens, float* books, void* scratch,
                          int batch, int dim, int t, int nb, int k, float decay, void* stream)
 {
-    if (!z_tokens || !books || !scratch) return fail(MVQ_EINVAL, "rvq_ema_step: null tensor");
     if (batch < 0 || t < 0 || dim <= 0 || dim > 128 || dim % 4 != 0 || nb <= 0 || k <= 0) return fail(MVQ_EINVAL, "rvq_ema_step: bad shape");
     if (batch * t == 0) return MVQ_OK;
+    if (!z_tokens || !books || !scratch) return fail(MVQ_EINVAL, "rvq_ema_step: null tensor");
     int32_t* idx = reinterpret_cast<int32_t*>(scratch);
     hipError_t e = mvq::launch_rvq_ema_forward(z_tokens, books, nullptr, idx, batch, dim, t, nb, k, 0, S(stream));
     if (e != hipSuccess) return hipfail(e, "rvq_ema_step(assign)");
@@ -292,10 +294,11 @@ int mvq_dac_rvq_f32(const float* z, const float* in_w, const float* in_b, const 
                     const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
                     int batch, int c, int t, int nq_use, int k, int dc, void* stream)
 {
-    if (!z || !zq || !codes || !latents || !in_w || !in_b || !codebook || !out_w || !out_b)
-        return fail(MVQ_EINVAL, "dac_rvq: null tensor");
     if (batch < 0 || t < 0 || (c != 1024 && c != 512 && c != 256) || dc != 8 || (k * dc) % 4 != 0 || nq_use <= 0 || k <= 0 || dc <= 0 || dc > 16)
         return fail(MVQ_EINVAL, "dac_rvq: bad shape B=%d C=%d T=%d nq=%d K=%d Dc=%d (C in {256,512,1024}, Dc = 8)", batch, c, t, nq_use, k, dc);
+    if (batch == 0 || t == 0) return MVQ_OK;
+    if (!z || !zq || !codes || !latents || !in_w || !in_b || !codebook || !out_w || !out_b)
+        return fail(MVQ_EINVAL, "dac_rvq: null tensor");
     const size_t lds = ((size_t)k * dc + k + (size_t)dc * c + 16 * (size_t)dc * 16 + 2 * (size_t)dc * 16 + 2 * 16 * 16) * sizeof(float);
     if (lds > 160 * 1024) return fail(MVQ_EUNSUPPORTED, "dac_rvq: K*Dc too large for LDS (%zu bytes)", lds);
     hipError_t e = mvq::launch_dac_rvq(z, in_w, in_b, codebook, out_w, out_b, zq, codes, latents, batch, c, t, nq_use, k, dc, S(stream));

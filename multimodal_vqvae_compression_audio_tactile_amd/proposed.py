@@ -167,6 +167,8 @@ class _ProposedBase(nn.Module):
         B, C, Tlat = zt.shape
         z_run = torch.zeros_like(zt)
         r_tokens = torch.empty(B, CODE_DIM, Tlat, device=zt.device, dtype=torch.float32) if want_tokens else None
+        if B == 0 or Tlat == 0:                                               # empty batch / clip shorter than a token
+            return z_run, r_tokens
         scale = self._scale_value()
         ln = self.tokennorm.ln
         for s in range(0, Tlat, AR_CHUNK_TOK):
