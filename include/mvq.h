@@ -175,6 +175,16 @@ int mvq_sub3d_f32(const float* a, size_t a_sb, size_t a_sc, const float* b, size
 int mvq_copy3d_f32(const float* a, size_t a_sb, size_t a_sc, float* y, size_t y_sb, size_t y_sc,
                    int batch, int c, int n, void* stream);
 
+/* ---- evaluation metrics next to the path ---------------------------------- */
+
+/* align_by_xcorr (Evaluation/dac_vcpwq_proposed6_latency.py:164-202): for every integer shift s in
+ * [-max_shift, max_shift] the correlation c(s) = sum(r_seg * e_seg) of two equal-length signals ref[t], est[t]
+ * (s<0: ref[-s:], est[:t+s]; s>0: ref[:t-s], est[s:]), each one fp32 fma chain in sample order; best_shift = first
+ * maximum in ascending s (strict >, start -1e18).  corr[2*max_shift+1], scratch[2*max_shift+1] int32, best_shift[1]
+ * (device).  One launch pair instead of 2*max_shift+1 reductions with a host comparison each. */
+int mvq_align_xcorr_f32(const float* ref, const float* est, int t, int max_shift, float* corr, int32_t* scratch,
+                        int32_t* best_shift, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

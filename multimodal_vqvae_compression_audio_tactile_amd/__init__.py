@@ -12,7 +12,7 @@ from . import ops, synth  # noqa: F401
 from ._lib import MvqError, build, lib  # noqa: F401
 from .dac import DAC, Decoder, Encoder, ResidualVectorQuantize, VectorQuantize, Snake1d, WNConv1d, WNConvTranspose1d  # noqa: F401
 from .proposed import (AllPredAR, CrossPredictor, PosEnc1D, ProposedEval, ResidualVQEMA, TokenNorm,  # noqa: F401
-                       psnr_batch, psnr_global_peak_db)
+                       psnr_batch, psnr_global_peak_db, align_by_xcorr, crop_match)
 
 
 def build_proposed(state_dict=None, rvq_books=8, rvq_embed=512, n_codebooks=32, device="cuda", cls=None):

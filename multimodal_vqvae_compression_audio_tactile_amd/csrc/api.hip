@@ -357,4 +357,13 @@ int mvq_copy3d_f32(const float* a, size_t a_sb, size_t a_sc, float* y, size_t y_
     return e == hipSuccess ? MVQ_OK : hipfail(e, "copy3d");
 }
 
+int mvq_align_xcorr_f32(const float* ref, const float* est, int t, int max_shift, float* corr, int32_t* scratch,
+                        int32_t* best_shift, void* stream)
+{
+    if (t < 0 || max_shift < 0) return fail(MVQ_EINVAL, "align_xcorr: bad shape");
+    if (!ref || !est || !corr || !scratch || !best_shift) return fail(MVQ_EINVAL, "align_xcorr: null tensor");
+    hipError_t e = mvq::launch_align_xcorr(ref, est, t, max_shift, corr, scratch, best_shift, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "align_xcorr");
+}
+
 }  // extern "C"

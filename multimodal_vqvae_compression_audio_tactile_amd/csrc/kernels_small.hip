@@ -516,4 +516,50 @@ hipError_t launch_strided3d(const float* a, size_t asb, size_t asc, const float*
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// align_by_xcorr: one thread per integer shift walks its correlation chain (sample order, the contract); a second
+// single-wave kernel takes the first maximum.  Replaces 401 separate torch reductions + host comparisons per file.
+// ------------------------------------------------------------------------------------------------
+__global__ void xcorr_kernel(const float* __restrict__ r, const float* __restrict__ e, int T, int max_shift,
+                             float* __restrict__ corr, int* __restrict__ valid)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > 2 * max_shift) return;
+    const int s = k - max_shift;
+    const int n = T - (s < 0 ? -s : s);
+    const float* rp = s < 0 ? r - s : r;
+    const float* ep = s > 0 ? e + s : e;
+    float c = 0.0f;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[u] = rp[i + u]; b[u] = ep[i + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c = dfma(a[u], b[u], c);
+    }
+    for (; i < n; ++i) c = dfma(rp[i], ep[i], c);
+    corr[k] = n > 0 ? c : 0.0f;
+    valid[k] = n > 0;
+}
+
+__global__ void xcorr_pick_kernel(const float* __restrict__ corr, const int* __restrict__ valid, int max_shift,
+                                  int* __restrict__ best_shift)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int best_s = 0; float best = -1e18f;
+    for (int k = 0; k <= 2 * max_shift; ++k)
+        if (valid[k] && corr[k] > best) { best = corr[k]; best_s = k - max_shift; }
+    *best_shift = best_s;
+}
+
+hipError_t launch_align_xcorr(const float* r, const float* e, int T, int max_shift, float* corr, int* scratch_valid,
+                              int* best_shift, hipStream_t s)
+{
+    const int n = 2 * max_shift + 1;
+    hipLaunchKernelGGL(xcorr_kernel, dim3((n + 63) / 64), dim3(64), 0, s, r, e, T, max_shift, corr, scratch_valid);
+    hipLaunchKernelGGL(xcorr_pick_kernel, dim3(1), dim3(64), 0, s, corr, scratch_valid, max_shift, best_shift);
+    return hipGetLastError();
+}
+
 }  // namespace mvq

@@ -28,6 +28,9 @@ hipError_t launch_gelu(const float* x, float* y, size_t n, hipStream_t s);
 hipError_t launch_strided3d(const float* a, size_t asb, size_t asc, const float* b2, size_t bsb, size_t bsc,
                             float* y, size_t ysb, size_t ysc, int B, int C, int n, hipStream_t s);
 
+hipError_t launch_align_xcorr(const float* r, const float* e, int T, int max_shift, float* corr, int* scratch_valid,
+                              int* best_shift, hipStream_t s);
+
 hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_out, int32_t* idx_out,
                                   int B, int D, int T, int nb, int K, int update_residual, hipStream_t s);
 hipError_t launch_ema_update(const float* z, const int32_t* idx, float* books, int B, int D, int T, int nb, int K,

@@ -267,3 +267,17 @@ def sub(a, b):
     check(_lib.lib().mvq_sub3d_f32(a.data_ptr(), 0, 0, b.data_ptr(), 0, 0, y.data_ptr(), 0, 0, 1, 1, n, _stream()),
           "mvq_sub3d_f32")
     return y
+
+
+def align_xcorr(ref, est, max_shift=200):
+    """Correlations c(s), s in [-max_shift, max_shift], of equal-length 1-D signals and the best shift (device int32)."""
+    ref = _dev(ref, "ref").reshape(-1); est = _dev(est, "est").reshape(-1)
+    if ref.numel() != est.numel():
+        raise MvqError("align_xcorr: crop_match the signals first (equal lengths)")
+    n = 2 * max_shift + 1
+    corr = torch.empty(n, device=ref.device, dtype=torch.float32)
+    scratch = torch.empty(n, device=ref.device, dtype=torch.int32)
+    best = torch.zeros(1, device=ref.device, dtype=torch.int32)
+    check(_lib.lib().mvq_align_xcorr_f32(ref.data_ptr(), est.data_ptr(), ref.numel(), max_shift, corr.data_ptr(),
+                                         scratch.data_ptr(), best.data_ptr(), _stream()), "mvq_align_xcorr_f32")
+    return corr, best

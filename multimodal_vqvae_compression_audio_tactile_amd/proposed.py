@@ -253,3 +253,25 @@ def psnr_global_peak_db(ref, est, peak, eps=1e-12):
     mse = torch.mean((ref - est) ** 2) + eps
     peak = max(float(peak), eps)
     return float(10.0 * torch.log10((peak * peak) / mse).cpu())
+
+
+def crop_match(a_1T, b_1T):
+    """Evaluation/dac_vcpwq_proposed6_latency.py:158-160."""
+    T = min(a_1T.shape[-1], b_1T.shape[-1])
+    return a_1T[..., :T], b_1T[..., :T]
+
+
+@torch.no_grad()
+def align_by_xcorr(ref_1T, est_1T, max_shift=200):
+    """Evaluation/dac_vcpwq_proposed6_latency.py:164-202: align est to ref by the integer shift that maximises the
+    cross-correlation.  All 2*max_shift+1 correlations run in one launch; ONE device->host read (the shift)."""
+    r = ref_1T.reshape(-1).to(torch.float32); e = est_1T.reshape(-1).to(torch.float32)
+    _, best = ops.align_xcorr(r, e, max_shift)
+    s = int(best.item())
+    if s < 0:
+        r_a = r[-s:]; e_a = e[: r_a.numel()]
+    elif s > 0:
+        r_a = r[:-s]; e_a = e[s: s + r_a.numel()]
+    else:
+        r_a = r; e_a = e[: r.numel()]
+    return r_a.unsqueeze(0), e_a.unsqueeze(0), s

@@ -479,3 +479,27 @@ void orc_tanh(const float* x, float* y, size_t n) { for (size_t i = 0; i < n; ++
 void orc_sin(const float* x, float* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = om_sin(x[i]); }
 void orc_exp(const float* x, float* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = om_exp(x[i]); }
 void orc_erf(const float* x, float* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = om_erf(x[i]); }
+
+/* ------------------------------------------------------------------------------------------------
+ * align_by_xcorr (Evaluation/dac_vcpwq_proposed6_latency.py:164-202): integer shift s in [-max_shift, max_shift]
+ * maximising c(s) = sum(r_seg * e_seg) with  s<0: r[-s:], e[:T+s] ; s>0: r[:T-s], e[s:T] ; s=0: r, e  (r, e same
+ * length T, as the caller crop_match()es them first).  First maximum in ascending s (strict `c > best`), start value
+ * -1e18.  Each c(s) is one fp32 fma chain in sample order.  corr_out[2*max_shift+1], returns best shift.
+ * ---------------------------------------------------------------------------------------------- */
+int orc_align_xcorr(const float* r, const float* e, int T, int max_shift, float* corr_out)
+{
+    int best_s = 0; float best = -1e18f;
+    for (int s = -max_shift; s <= max_shift; ++s) {
+        int n = T - (s < 0 ? -s : s);
+        float c = 0.0f;
+        int valid = n > 0;
+        if (valid) {
+            const float* rp = s < 0 ? r - s : r;
+            const float* ep = s > 0 ? e + s : e;
+            for (int i = 0; i < n; ++i) c = om_fma(rp[i], ep[i], c);
+        }
+        if (corr_out) corr_out[s + max_shift] = valid ? c : 0.0f;
+        if (valid && c > best) { best = c; best_s = s; }
+    }
+    return best_s;
+}

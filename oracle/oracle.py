@@ -401,3 +401,20 @@ def psnr_global_peak_db(ref, est, peak, eps=1e-12):
     mse = ((ref - est) ** 2).mean() + eps
     peak = max(float(peak), eps)
     return float(10.0 * np.log10(peak * peak / mse))
+
+
+def align_by_xcorr(ref_1T, est_1T, max_shift=200):
+    """Evaluation/dac_vcpwq_proposed6_latency.py:164-202 -> (ref_aligned[1,T'], est_aligned[1,T'], best_shift, corr)."""
+    r_, rp = _f(np.reshape(ref_1T, -1))
+    e_, ep = _f(np.reshape(est_1T, -1))
+    assert r_.size == e_.size
+    T = r_.size
+    corr = np.zeros(2 * max_shift + 1, np.float32)
+    s = lib().orc_align_xcorr(rp, ep, T, int(max_shift), corr.ctypes.data_as(f32p))
+    if s < 0:
+        r_a = r_[-s:]; e_a = e_[:r_a.size]
+    elif s > 0:
+        r_a = r_[:-s]; e_a = e_[s:s + r_a.size]
+    else:
+        r_a, e_a = r_, e_[:r_.size]
+    return r_a[None], e_a[None], int(s), corr

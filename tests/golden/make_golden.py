@@ -11,6 +11,7 @@ patched) and records inputs-by-seed + expected outputs of:
   G3 CrossPredictor.forward           (Training/compare_dacvsproposal_5.py:226-244), eval mode
   G4 ProposedEval.encode_latents / forward_eval (Evaluation/dac_vcpwq_proposed6_latency.py:451-487) driven with the
      torch restatement of the DAC backbones as A_ENC / A_QUANT / T_ENC / T_DEC (the real `dac` package is absent)
+  G6 align_by_xcorr                   (Evaluation/dac_vcpwq_proposed6_latency.py:164-202)
   G5 psnr_batch / psnr_global_peak_db (Evaluation/compare_dacvsproposal_5_eval.py:180-185, ...6_latency.py:204-214)
 Only data is stored (arrays), never reference source.  Inputs are re-created from seeds by tests/golden_inputs.py.
 """
@@ -108,6 +109,13 @@ def main():
           "psnr_global": np.array([ev.psnr_global_peak_db(torch.from_numpy(ref[i]), torch.from_numpy(est[i]), 4.3857)
                                    for i in range(3)], np.float64)}
     np.savez_compressed(OUT / "g5_psnr.npz", **g5)
+    # ---- G6: align_by_xcorr (Evaluation/dac_vcpwq_proposed6_latency.py:164-202)
+    g6 = {}
+    for name, (T, shift, noise, seed) in gi.ALIGN_CASES.items():
+        ref, est = gi.align_inputs(T, shift, noise, seed)
+        r_a, e_a, s = ev.align_by_xcorr(torch.from_numpy(ref), torch.from_numpy(est), 200)
+        g6[f"{name}.shift"] = np.array(s); g6[f"{name}.ref_a"] = r_a.numpy(); g6[f"{name}.est_a"] = e_a.numpy()
+    np.savez_compressed(OUT / "g6_align.npz", **g6)
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size // 1024, "KiB")
 

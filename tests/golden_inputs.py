@@ -49,3 +49,18 @@ def model_state(seed, books, K):
 def pe_inputs(B, seed):
     from multimodal_vqvae_compression_audio_tactile_amd import synth
     return synth.audio_segments(B, seed=seed, T=T_SHORT), synth.tactile_segments(B, seed=seed, T=T_SHORT)
+
+
+# name: (T, true_shift, noise, seed)   -- signals at the tactile rate (3 kHz), max_shift 200 as in the reference
+ALIGN_CASES = {"lag+37": (9000, 37, 0.05, 401), "lag-120": (6000, -120, 0.2, 402), "lag0": (3000, 0, 0.0, 403),
+               "short": (150, 20, 0.1, 404)}
+
+
+def align_inputs(T, shift, noise, seed):
+    r = np.random.default_rng(seed)
+    w = r.standard_normal(T + 600)
+    base = (0.5 * w + 0.3 * np.roll(w, 1) + 0.2 * np.roll(w, 2)).astype(np.float32)      # lightly coloured noise
+    base = base / (np.abs(base).max() + 1e-6)
+    ref = base[300:300 + T].copy()
+    est = base[300 - shift:300 - shift + T] + noise * r.standard_normal(T).astype(np.float32)
+    return ref[None].astype(np.float32), est[None].astype(np.float32)
