@@ -115,7 +115,10 @@ int mvq_conv_kernel_name(int batch, int cin, int cout, int ks, int stride, int d
         a.Mrows = cout; a.Mpad = mvq::conv_mpad(cout); a.Ncols = conv_out_len(tin, ks, stride, dil, pad); a.pad = pad;
         a.Tout = a.Ncols; a.up_s = 1;
         e = dispatch_conv1d(a, ks, stride, dil, nullptr);
-        if (e != hipSuccess) snprintf(buf, len, "conv1d_direct_kernel");
+        if (e != hipSuccess)
+            snprintf(buf, len, "%s", (cin == 1 && ks == 7 && stride == 1 && dil == 1) ? "conv1d_cin1_kernel<7>"
+                                   : (cout == 1 && ks == 7 && stride == 1 && dil == 1) ? "conv1d_cout1_kernel<7>"
+                                                                                       : "conv1d_direct_kernel");
     }
     return MVQ_OK;
 }

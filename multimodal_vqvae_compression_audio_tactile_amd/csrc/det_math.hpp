@@ -95,11 +95,30 @@ __device__ __forceinline__ float det_gelu(float x)
     return (0.5f * x) * (1.0f + det_erf(x * 0.707106781186547524f));
 }
 
+// sin(y)^2 with period-pi reduction and ONE even polynomial (no quadrant select): ~17 VALU ops instead of ~35 for
+// sin() then squaring -- Snake is the dominant VALU cost of the conv staging loops and epilogues.
+__device__ __forceinline__ float det_sin2(float y)
+{
+    const float n = __builtin_rintf(y * 0.318309886183790672f);
+    float r = dfma(-n, 3.140625f, y);
+    r = dfma(-n, 9.67502593994140625e-4f, r);
+    r = dfma(-n, 1.509957990978376e-7f, r);
+    const float u = r * r;
+    float p = dfma(u, 2.04724070e-11f, -1.56613913e-09f);
+    p = dfma(u, p, 9.39683479e-08f);
+    p = dfma(u, p, -4.27555983e-06f);
+    p = dfma(u, p, 1.41093474e-04f);
+    p = dfma(u, p, -3.17460317e-03f);
+    p = dfma(u, p, 4.44444444e-02f);
+    p = dfma(u, p, -3.33333333e-01f);
+    p = dfma(u, p, 1.0f);
+    return u * p;
+}
+
 // inv_alpha = 1.0f / (alpha + 1e-9f), precomputed once per channel (same IEEE division everywhere)
 __device__ __forceinline__ float det_snake(float x, float alpha, float inv_alpha)
 {
-    const float s = det_sin(alpha * x);
-    return dfma(inv_alpha, s * s, x);
+    return dfma(inv_alpha, det_sin2(alpha * x), x);
 }
 
 }  // namespace mvq

@@ -120,12 +120,36 @@ static inline float om_gelu(float x)
     return (0.5f * x) * (1.0f + om_erf(x * RSQRT2));
 }
 
+/* ---- sin(y)^2 directly: period pi, even in the reduced argument -> one polynomial, no quadrant logic --------
+ *   n = rint(y/pi) ; r = y - n*pi (3-term Cody-Waite) in [-pi/2, pi/2] ; u = r*r ;
+ *   sin^2 r = u - u^2/3 + 2u^3/45 - u^4/315 + ...  (Taylor, 9 terms: truncation < 3e-9 at |r| = pi/2)            */
+static inline float om_sin2(float y)
+{
+    const float INV_PI = 0.318309886183790672f;
+    const float PI_1 = 3.140625f;                  /* pi split: 8 significant bits */
+    const float PI_2 = 9.67502593994140625e-4f;
+    const float PI_3 = 1.509957990978376e-7f;
+    float n = rintf(y * INV_PI);
+    float r = om_fma(-n, PI_1, y);
+    r = om_fma(-n, PI_2, r);
+    r = om_fma(-n, PI_3, r);
+    float u = r * r;
+    float p = om_fma(u, 2.04724070e-11f, -1.56613913e-09f);
+    p = om_fma(u, p, 9.39683479e-08f);
+    p = om_fma(u, p, -4.27555983e-06f);
+    p = om_fma(u, p, 1.41093474e-04f);
+    p = om_fma(u, p, -3.17460317e-03f);
+    p = om_fma(u, p, 4.44444444e-02f);
+    p = om_fma(u, p, -3.33333333e-01f);
+    p = om_fma(u, p, 1.0f);
+    return u * p;
+}
+
 /* Snake1d: x + (alpha + 1e-9)^-1 * sin(alpha*x)^2   [upstream dac/nn/layers.py snake()] */
 static inline float om_snake(float x, float alpha)
 {
-    float s = om_sin(alpha * x);
     float inv = 1.0f / (alpha + 1e-9f);
-    return om_fma(inv, s * s, x);
+    return om_fma(inv, om_sin2(alpha * x), x);
 }
 
 #endif /* ORACLE_DET_MATH_H */

@@ -12,6 +12,10 @@ def test_det_math_accuracy(orc):
     r = np.random.default_rng(0)
     x = r.uniform(-60, 60, 400000).astype(np.float32)
     assert np.abs(orc.sin(x) - np.sin(x.astype(np.float64))).max() < 1.5e-7
+    x = r.uniform(-200, 200, 400000).astype(np.float32)
+    assert np.abs(orc.sin2(x) - np.sin(x.astype(np.float64)) ** 2).max() < 2.5e-7       # Snake's sin^2 (period-pi form)
+    xs = r.uniform(-3, 3, 100000).astype(np.float32)
+    assert np.abs(orc.sin2(xs) - np.sin(xs.astype(np.float64)) ** 2).max() < 2.5e-7
     x = r.uniform(-87, 20, 400000).astype(np.float32)
     ref = np.exp(x.astype(np.float64))
     assert (np.abs(orc.exp(x) - ref) / ref).max() < 2.5e-7
