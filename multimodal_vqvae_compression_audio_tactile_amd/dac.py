@@ -31,11 +31,16 @@ DEC_RATES = (8, 5, 4, 2)
 
 
 class _Packed:
-    """Cache of derived device tensors keyed on the (identity, version, storage) of their source parameters."""
+    """Cache of derived device tensors keyed on the (identity, version, storage) of their source parameters.
+    In-place edits through ``param.data`` bypass the version counter: call ``.invalidate()`` after such an edit (the
+    backbones are frozen in the reference, Training/compare_dacvsproposal_5.py:283-284; load_state_dict / .to() are seen)."""
 
     def __init__(self):
         self._key = None
         self.value = None
+
+    def invalidate(self):
+        self._key = None
 
     def get(self, params, make):
         key = tuple((id(p), p._version, p.data_ptr(), str(p.device)) for p in params)

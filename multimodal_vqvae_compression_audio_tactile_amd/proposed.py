@@ -119,8 +119,9 @@ class ResidualVQEMA(nn.Module):
         self._stack = _Packed()
 
     def stacked(self) -> torch.Tensor:
-        bs = list(self.books)
-        return self._stack.get(bs, lambda: torch.stack([b.detach().float() for b in bs]).contiguous())
+        """[n_books, K, D] view for the kernel.  Re-stacked on every call (1.5 MB at most): the reference updates the
+        books through ``.data`` (ema_step), which no version counter sees, so nothing derived from them is cached."""
+        return torch.stack([b.detach().float() for b in self.books]).contiguous()
 
     @torch.no_grad()
     def forward(self, z, n_books_use: Optional[int] = None, return_indices: bool = False):
@@ -130,7 +131,7 @@ class ResidualVQEMA(nn.Module):
 
     @torch.no_grad()
     def ema_step(self, z_tokens):
-        books = self.stacked().clone()
+        books = self.stacked()
         ops.rvq_ema_step_(z_tokens, books, self.decay)
         for i, p in enumerate(self.books):
             p.data.copy_(books[i])

@@ -99,3 +99,50 @@ def test_whole_file_audio_shorter_than_tactile(orc, dev):
     want = orc.proposed_encode_latents(_np(sd), a.numpy(), t.numpy())
     got = net.encode_latents(a.to(dev), t.to(dev))
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_corpus_sharding_equivalence(dev):
+    """BASELINE.json configs[3]: clips of different lengths cut into 1-s segments and sharded over ranks (no data-path
+    collective) give exactly the results of one unsharded batch, whichever rank a segment lands on."""
+    from multimodal_vqvae_compression_audio_tactile_amd import build_proposed, dist as mdist, synth
+    sd = synth.proposed_model_state(5, rvq_books=3, rvq_embed=128)
+    net = build_proposed(sd, rvq_books=3, rvq_embed=128, device=dev)
+    seg = 320 * 20                                            # shortened "1-s" segment keeps the test fast
+    lens = [1, 3, 2, 4, 1, 2]                                 # clip lengths in segments
+    a = synth.audio_segments(sum(lens), seed=31, T=seg).to(dev)
+    t = synth.tactile_segments(sum(lens), seed=31, T=seg).to(dev)
+    full = net.forward_eval(a, t)
+    n = full.shape[0]
+    for world in (2, 4, 8):
+        got = torch.empty_like(full)
+        for rank in range(world):
+            idx = mdist.shard_round_robin(n, rank, world)
+            if idx:
+                got[idx] = net.forward_eval(a[idx], t[idx])
+        assert torch.equal(got, full)
+        s, e = mdist.shard_range(n, world - 1, world)
+        if e > s:
+            assert torch.equal(net.forward_eval(a[s:e], t[s:e]), full[s:e])
+
+
+def test_training_forward_then_ema_step(orc, dev):
+    """BASELINE.json configs[4], forward + codebook-EMA part: AllPredAR.forward_step -> r_tokens -> vq.ema_step equals the
+    oracle's ema_step on the oracle's r_tokens, books bit for bit (Training/compare_dacvsproposal_5.py:382,396-397)."""
+    from multimodal_vqvae_compression_audio_tactile_amd import AllPredAR, build_proposed, synth
+    sd = synth.proposed_model_state(17, rvq_books=3, rvq_embed=128)
+    net = build_proposed(sd, rvq_books=3, rvq_embed=128, device=dev, cls=AllPredAR)
+    a = synth.audio_segments(2, seed=6, T=T_SHORT); t = synth.tactile_segments(2, seed=6, T=T_SHORT)
+    out = net.forward_step(a.to(dev), t.to(dev))
+    _, aux = orc.proposed_encode_latents(_np(sd), a.numpy(), t.numpy(), return_aux=True)
+    assert np.array_equal(out["r_tokens"].cpu().numpy(), aux["r_tokens"])
+    before = [b.detach().clone() for b in net.vq.books]
+    net.vq.ema_step(out["r_tokens"])
+    want, _ = orc.rvq_ema_step(aux["r_tokens"], [sd[f"vq.books.{i}"].numpy() for i in range(3)], 0.99)
+    for i, b in enumerate(net.vq.books):
+        assert np.array_equal(b.detach().cpu().numpy(), want[i])
+        assert not torch.equal(b.detach(), before[i])
+    # the updated books are what the next forward uses
+    out2 = net.forward_step(a.to(dev), t.to(dev))
+    sd2 = dict(_np(sd)); sd2.update({f"vq.books.{i}": want[i] for i in range(3)})
+    _, aux2 = orc.proposed_encode_latents(sd2, a.numpy(), t.numpy(), return_aux=True)
+    assert np.array_equal(out2["r_tokens"].cpu().numpy(), aux2["r_tokens"])
