@@ -200,11 +200,31 @@ class _ProposedBase(nn.Module):
 class ProposedEval(_ProposedBase):
     """Evaluation/dac_vcpwq_proposed6_latency.py:437-487."""
 
+    def _encode_branches(self, a_1T, t_1T):
+        """qa = A_QUANT(A_ENC(a)) and zt = T_ENC(t) are independent.  In the latency regime (few segments: every
+        launch underfills the 256 CUs) the audio branch runs on a second HIP stream beside the tactile branch."""
+        if a_1T.shape[0] > 4 or not a_1T.is_cuda:
+            za = self.A_ENC(a_1T)
+            qa, *_ = self.A_QUANT(za)
+            return qa, self.T_ENC(t_1T)
+        cur = torch.cuda.current_stream()
+        side = getattr(self, "_side_stream", None)
+        if side is None or side.device != a_1T.device:
+            side = torch.cuda.Stream(device=a_1T.device)
+            self._side_stream = side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            za = self.A_ENC(a_1T)
+            qa, *_ = self.A_QUANT(za)
+        zt = self.T_ENC(t_1T)
+        cur.wait_stream(side)
+        for x in (za, qa):
+            x.record_stream(cur)
+        return qa, zt
+
     @torch.no_grad()
     def encode_latents(self, a_1T, t_1T, books_use=None):
-        za = self.A_ENC(a_1T)
-        qa, *_ = self.A_QUANT(za)
-        zt = self.T_ENC(t_1T)
+        qa, zt = self._encode_branches(a_1T, t_1T)
         z_run, _ = self._ar_latents(qa, zt, books_use)
         return z_run
 
