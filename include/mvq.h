@@ -185,6 +185,29 @@ int mvq_copy3d_f32(const float* a, size_t a_sb, size_t a_sc, float* y, size_t y_
 int mvq_align_xcorr_f32(const float* ref, const float* est, int t, int max_shift, float* corr, int32_t* scratch,
                         int32_t* best_shift, void* stream);
 
+/* ---- backward w.r.t. the decoder input (weights are frozen in the reference) ----- */
+
+/* Input-gradient of a conv is a conv with a transformed weight image, so it runs on the same MFMA kernels:
+ *   forward Conv1d w[Cout,Cin,ks], stride 1:           wp = mvq_conv1d_pack_dgrad_f32(w)            (flip + transpose)
+ *   forward ConvTranspose1d w[Cin,Cout,ks], stride s:  wp = mvq_conv_transpose1d_pack_dgrad_f32(w)  (a strided conv)
+ * size query: mvq_conv1d_dgrad_packed_floats(cin, cout, ks) with cin = channels of the forward INPUT. */
+size_t mvq_conv1d_dgrad_packed_floats(int cin, int cout, int ks);
+int mvq_conv1d_pack_dgrad_f32(const float* w, float* wp, int cin, int cout, int ks, void* stream);
+int mvq_conv_transpose1d_pack_dgrad_f32(const float* w, float* wp, int cin, int cout, int ks, void* stream);
+
+/* gx[B,cin,tin] = ( dgrad-conv(gy[B,cout,tout]) ) * d snake(dsnake_src)/dx  + residual
+ * (cin, tin, cout, tout, ks, stride, dil, pad describe the FORWARD layer: stride 1 for Conv1d, the up-sampling stride
+ * for a ConvTranspose1d).  dsnake_src[B,cin,tin] = saved input of the Snake1d in front of the forward layer and
+ * dsnake_alpha[cin] its alpha (both NULL: no Snake in front); residual[B,cin,tin] = gradient arriving over a skip
+ * connection or NULL.  Chain order: forward output channel ascending, then tap ascending. */
+int mvq_conv1d_dgrad_f32(const float* gy, const float* wp_dgrad, const float* dsnake_src, const float* dsnake_alpha,
+                         const float* residual, float* gx,
+                         int batch, int cin, int tin, int cout, int tout, int ks, int stride, int dil, int pad,
+                         void* stream);
+
+/* out = g * (1 - y*y): backward of the decoder's final tanh (y = saved output). */
+int mvq_mul_dtanh_f32(const float* g, const float* y, float* out, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

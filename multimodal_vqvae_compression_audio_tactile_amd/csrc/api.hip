@@ -157,7 +157,7 @@ int mvq_conv1d_dual_f32(const float* x, const float* wp, const float* bias, cons
     hipError_t e = dispatch_conv1d(a, ks, stride, dil, S(stream));
     if (e == hipErrorInvalidValue) {
         (void)hipGetLastError();
-        mvq::DirectConvArgs d{x, wp, bias, alpha_in, residual, alpha_out, y, batch, cin, tin, cout, tout, ks, stride, dil, pad, mpad, act, y2, alpha2};
+        mvq::DirectConvArgs d{x, wp, bias, alpha_in, residual, alpha_out, y, batch, cin, tin, cout, tout, ks, stride, dil, pad, mpad, act, y2, alpha2, nullptr, nullptr};
         e = mvq::launch_conv1d_direct(d, S(stream));
     }
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d");
@@ -257,7 +257,7 @@ int mvq_conv_transpose1d_dual_f32(const float* x, const float* wp, const float* 
     }
     if (e == hipErrorInvalidValue) {
         (void)hipGetLastError();
-        mvq::DirectConvArgs d{x, wp, bias, alpha_in, nullptr, alpha_out, y, batch, cin, tin, cout, tout, 2 * stride, stride, 1, pad, mpad, 0, y2, alpha2};
+        mvq::DirectConvArgs d{x, wp, bias, alpha_in, nullptr, alpha_out, y, batch, cin, tin, cout, tout, 2 * stride, stride, 1, pad, mpad, 0, y2, alpha2, nullptr, nullptr};
         e = mvq::launch_convtr_direct(d, S(stream));
     }
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv_transpose1d");
@@ -367,6 +367,65 @@ int mvq_align_xcorr_f32(const float* ref, const float* est, int t, int max_shift
     if (!ref || !est || !corr || !scratch || !best_shift) return fail(MVQ_EINVAL, "align_xcorr: null tensor");
     hipError_t e = mvq::launch_align_xcorr(ref, est, t, max_shift, corr, scratch, best_shift, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "align_xcorr");
+}
+
+/* ---- backward (input-gradient) entry points: SURVEY.md section 8f row f1 ------------------------------------- */
+
+size_t mvq_conv1d_dgrad_packed_floats(int cin, int cout, int ks)
+{
+    if (cin <= 0 || cout <= 0 || ks <= 0) return 0;
+    return (size_t)cout * ks * mvq::conv_mpad(cin);
+}
+
+int mvq_conv1d_pack_dgrad_f32(const float* w, float* wp, int cin, int cout, int ks, void* stream)
+{
+    if (!w || !wp || cin <= 0 || cout <= 0 || ks <= 0) return fail(MVQ_EINVAL, "conv1d_pack_dgrad: bad argument");
+    hipError_t e = mvq::launch_pack_conv1d_dgrad(w, wp, cin, cout, ks, mvq::conv_mpad(cin), S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_pack_dgrad");
+}
+
+int mvq_conv_transpose1d_pack_dgrad_f32(const float* w, float* wp, int cin, int cout, int ks, void* stream)
+{
+    if (!w || !wp || cin <= 0 || cout <= 0 || ks <= 0) return fail(MVQ_EINVAL, "conv_transpose1d_pack_dgrad: bad argument");
+    hipError_t e = mvq::launch_pack_convtr_dgrad(w, wp, cin, cout, ks, mvq::conv_mpad(cin), S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv_transpose1d_pack_dgrad");
+}
+
+int mvq_conv1d_dgrad_f32(const float* gy, const float* wp_dgrad, const float* dsnake_src, const float* dsnake_alpha,
+                         const float* residual, float* gx,
+                         int batch, int cin, int tin, int cout, int tout, int ks, int stride, int dil, int pad, void* stream)
+{
+    /* gradient w.r.t. the input of a forward conv x[B,cin,tin] -> y[B,cout,tout]:
+     *   stride 1 : conv1d over gy with the flipped/transposed image, same dilation, padding (ks-1)*dil - pad
+     *   (forward was a ConvTranspose1d with kernel ks, stride, pad; its input-gradient is a strided conv): stride > 1 */
+    if (batch < 0 || cin <= 0 || cout <= 0 || tin < 0 || tout < 0 || ks <= 0 || stride <= 0 || dil <= 0 || pad < 0)
+        return fail(MVQ_EINVAL, "conv1d_dgrad: bad shape");
+    if (batch == 0 || tin == 0) return MVQ_OK;
+    if (!gy || !wp_dgrad || !gx) return fail(MVQ_EINVAL, "conv1d_dgrad: null tensor");
+    if ((dsnake_src != nullptr) != (dsnake_alpha != nullptr)) return fail(MVQ_EINVAL, "conv1d_dgrad: dsnake_src and dsnake_alpha go together");
+    const int bpad = stride == 1 ? (ks - 1) * dil - pad : pad;
+    if (bpad < 0) return fail(MVQ_EUNSUPPORTED, "conv1d_dgrad: padding larger than the receptive field");
+    const int olen = conv_out_len(tout, ks, stride, dil, bpad);
+    if (olen != tin) return fail(MVQ_EINVAL, "conv1d_dgrad: shapes inconsistent (got %d input-gradient samples, expected %d)", olen, tin);
+    mvq::ConvArgs a{};
+    a.x = gy; a.wp = wp_dgrad; a.residual = residual; a.y = gx;
+    a.B = batch; a.Cin = cout; a.Tin = tout; a.Cout = cin; a.Tout = tin; a.pad = bpad; a.Mpad = mvq::conv_mpad(cin);
+    a.Mrows = cin; a.Ncols = tin; a.up_s = 1; a.dsn_src = dsnake_src; a.dsn_alpha = dsnake_alpha;
+    hipError_t e = dispatch_conv1d(a, ks, stride, dil, S(stream));
+    if (e == hipErrorInvalidValue) {
+        (void)hipGetLastError();
+        mvq::DirectConvArgs d{gy, wp_dgrad, nullptr, nullptr, residual, nullptr, gx, batch, cout, tout, cin, tin, ks, stride, dil, bpad,
+                              a.Mpad, 0, nullptr, nullptr, dsnake_src, dsnake_alpha};
+        e = mvq::launch_conv1d_direct(d, S(stream));
+    }
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_dgrad");
+}
+
+int mvq_mul_dtanh_f32(const float* g, const float* y, float* out, size_t n, void* stream)
+{
+    if ((!g || !y || !out) && n) return fail(MVQ_EINVAL, "mul_dtanh: null tensor");
+    hipError_t e = mvq::launch_mul_dtanh(g, y, out, n, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "mul_dtanh");
 }
 
 }  // extern "C"

@@ -54,6 +54,10 @@ struct ConvArgs {
     // would evaluate it M/BM times per element); the consumer then needs no alpha_in.
     float* y2;
     const float* alpha2;
+    // backward (dgrad) epilogue: v = acc * d snake(dsn_src)/dx  (+ residual) -- the Snake1d backward of the layer in
+    // front, fused behind the input-gradient conv; dsn_src[B,Cout,Tout] is that Snake's saved input, dsn_alpha[Cout].
+    const float* dsn_src;
+    const float* dsn_alpha;
     char* name_out;         // host only: when set, launchers write the kernel instantiation name here and do not launch
     int name_len;
 };
@@ -432,6 +436,12 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     f32x4 v = *reinterpret_cast<const f32x4*>(Ct + row * C::BNP + 4 * c4);
                     const size_t off = ((size_t)b * a.Cout + m) * a.Tout + n;
                     v.x = v.x + bv; v.y = v.y + bv; v.z = v.z + bv; v.w = v.w + bv;
+                    if (a.dsn_src) {
+                        const float ad = a.dsn_alpha[m], id = 1.0f / (ad + 1e-9f);
+                        const f32x4 sv = *reinterpret_cast<const f32x4*>(a.dsn_src + off);
+                        v.x = v.x * det_dsnake(sv.x, ad, id); v.y = v.y * det_dsnake(sv.y, ad, id);
+                        v.z = v.z * det_dsnake(sv.z, ad, id); v.w = v.w * det_dsnake(sv.w, ad, id);
+                    }
                     if (has_res) {
                         const f32x4 rv = *reinterpret_cast<const f32x4*>(a.residual + off);
                         v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
@@ -460,6 +470,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 if (m < a.Mrows && n < a.Ncols) {
                     const size_t off = ((size_t)b * a.Cout + m) * a.Tout + n;
                     float v = Ct[row * C::BNP + col] + (ep_bias ? ep_bias[m] : 0.0f);
+                    if (a.dsn_src) { const float ad = a.dsn_alpha[m]; v = v * det_dsnake(a.dsn_src[off], ad, 1.0f / (ad + 1e-9f)); }
                     if (has_res) v = v + a.residual[off];
                     if (a.y2) { const float a2 = a.alpha2[m]; a.y2[off] = det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
                     if (snake_out) { const float al = a.alpha_out[m]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
@@ -552,7 +563,8 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
     a.vec4 = (a.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     a.ovec4 = (a.Tout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
               (!a.residual || (reinterpret_cast<uintptr_t>(a.residual) & 15) == 0) &&
-              (!a.y2 || (reinterpret_cast<uintptr_t>(a.y2) & 15) == 0);
+              (!a.y2 || (reinterpret_cast<uintptr_t>(a.y2) & 15) == 0) &&
+              (!a.dsn_src || (reinterpret_cast<uintptr_t>(a.dsn_src) & 15) == 0);
     const size_t lds = (size_t)C::LDS_FLOATS * 4 + (a.alpha_in ? (size_t)2 * a.Cin * 4 : 0);
     auto kern = conv1d_mfma_kernel<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS>;
     static bool attr_set = false;

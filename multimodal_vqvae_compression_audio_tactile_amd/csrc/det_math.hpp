@@ -121,4 +121,11 @@ __device__ __forceinline__ float det_snake(float x, float alpha, float inv_alpha
     return dfma(inv_alpha, det_sin2(alpha * x), x);
 }
 
+// d snake(x)/dx = 1 + (alpha/(alpha+1e-9)) * sin(2*alpha*x)   (backward of Snake1d)
+__device__ __forceinline__ float det_dsnake(float x, float alpha, float inv_alpha)
+{
+    const float ax = alpha * x;
+    return dfma(alpha * inv_alpha, det_sin(ax + ax), 1.0f);
+}
+
 }  // namespace mvq

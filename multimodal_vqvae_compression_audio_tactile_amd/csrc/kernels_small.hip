@@ -79,6 +79,56 @@ hipError_t launch_pack_convtr(const float* w, float* wp, int cin, int cout, int 
     return hipGetLastError();
 }
 
+// dgrad weight images (the input-gradient of a conv is a conv with transformed weights):
+//   Conv1d w[Cout,Cin,ks] (stride 1, symmetric padding):  dX = conv1d(dY, w'),  w'[ci,co,k] = w[co,ci,ks-1-k]
+//      packed  wp[(co*ks + k) * Mpad + ci] = w[co, ci, ks-1-k]          (K index = (co, k), rows = ci)
+//   ConvTranspose1d w[Cin,Cout,ks] (stride s, padding p): dX = conv1d(dY, w, stride s, pad p) with out = Cin, in = Cout
+//      packed  wp[(co*ks + k) * Mpad + ci] = w[ci, co, k]
+__global__ void pack_conv1d_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                         int cin, int cout, int ks, int mpad, int transposed)
+{
+    const size_t total = (size_t)cout * ks * mpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % mpad);
+        const size_t row = i / mpad;
+        const int k = (int)(row % ks);
+        const int co = (int)(row / ks);
+        float v = 0.0f;
+        if (ci < cin) v = transposed ? w[((size_t)ci * cout + co) * ks + k] : w[((size_t)co * cin + ci) * ks + (ks - 1 - k)];
+        wp[i] = v;
+    }
+}
+
+hipError_t launch_pack_conv1d_dgrad(const float* w, float* wp, int cin, int cout, int ks, int mpad, hipStream_t s)
+{
+    const size_t total = (size_t)cout * ks * mpad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_conv1d_dgrad_kernel, dim3(blocks), dim3(256), 0, s, w, wp, cin, cout, ks, mpad, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_convtr_dgrad(const float* w, float* wp, int cin, int cout, int ks, int mpad, hipStream_t s)
+{
+    const size_t total = (size_t)cout * ks * mpad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_conv1d_dgrad_kernel, dim3(blocks), dim3(256), 0, s, w, wp, cin, cout, ks, mpad, 1);
+    return hipGetLastError();
+}
+
+__global__ void mul_dtanh_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ out, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = g[i] * dfma(-y[i], y[i], 1.0f);
+}
+
+hipError_t launch_mul_dtanh(const float* g, const float* y, float* out, size_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(mul_dtanh_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, y, out, n);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // direct conv1d: one thread per output sample, chain over (ci, kk).  Reads the PACKED weight image so
 // that callers hold one weight format.  Used where the GEMM view has no dense tile: Cin = 1 (encoder
@@ -108,6 +158,7 @@ __global__ void conv1d_direct_kernel(DirectConvArgs a)
             }
         }
         float v = acc + (a.bias ? a.bias[co] : 0.0f);
+        if (a.dsn_src) { const float ad = a.dsn_alpha[co]; v = v * det_dsnake(a.dsn_src[i], ad, 1.0f / (ad + 1e-9f)); }
         if (a.residual) v = v + a.residual[i];
         if (a.y2) { const float a2 = a.alpha2[co]; a.y2[i] = det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
         if (a.alpha_out) { const float al = a.alpha_out[co]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
@@ -135,7 +186,8 @@ __global__ __launch_bounds__(256) void conv1d_cin1_kernel(DirectConvArgs a)
         const int g = t0 - a.pad + i * a.dil;            // dil == 1 for this kernel
         xv[i] = (g >= 0 && g < a.Tin) ? xr[g] : 0.0f;
     }
-    float al = 0.0f, inv = 0.0f, a2 = 0.0f, i2 = 0.0f;
+    float al = 0.0f, inv = 0.0f, a2 = 0.0f, i2 = 0.0f, ad = 0.0f, idv = 0.0f;
+    if (a.dsn_src) { ad = a.dsn_alpha[co]; idv = 1.0f / (ad + 1e-9f); }
     if (a.alpha_out) { al = a.alpha_out[co]; inv = 1.0f / (al + 1e-9f); }
     if (a.y2) { a2 = a.alpha2[co]; i2 = 1.0f / (a2 + 1e-9f); }
     const size_t off = ((size_t)b * a.Cout + co) * a.Tout + t0;
@@ -146,6 +198,7 @@ __global__ __launch_bounds__(256) void conv1d_cin1_kernel(DirectConvArgs a)
 #pragma unroll
         for (int k = 0; k < KS; ++k) acc = dfma(w[k], xv[j + k], acc);
         float v = acc + bv;
+        if (a.dsn_src && t0 + j < a.Tout) v = v * det_dsnake(a.dsn_src[off + j], ad, idv);
         o2[j] = a.y2 ? det_snake(v, a2, i2) : 0.0f;
         if (a.alpha_out) v = det_snake(v, al, inv);
         if (a.act == 1) v = det_tanh(v);
@@ -211,7 +264,7 @@ hipError_t launch_conv1d_direct(const DirectConvArgs& a, hipStream_t s)
         hipLaunchKernelGGL(conv1d_cin1_kernel<7>, grid, dim3(256), 0, s, a);
         return hipGetLastError();
     }
-    if (a.Cout == 1 && a.ks == 7 && a.stride == 1 && a.dil == 1 && !a.alpha_in && !a.y2 && a.Cin * 7 * 4 <= 48 * 1024) {
+    if (a.Cout == 1 && a.ks == 7 && a.stride == 1 && a.dil == 1 && !a.alpha_in && !a.y2 && !a.dsn_src && a.Cin * 7 * 4 <= 48 * 1024) {
         dim3 grid((unsigned)((a.Tout + 1023) / 1024), (unsigned)a.B);
         hipLaunchKernelGGL(conv1d_cout1_kernel<7>, grid, dim3(256), (size_t)a.Cin * 7 * sizeof(float), s, a);
         return hipGetLastError();

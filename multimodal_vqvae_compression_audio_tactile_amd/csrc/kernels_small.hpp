@@ -11,6 +11,7 @@ struct DirectConvArgs {
     const float* alpha_out; float* y;
     int B, Cin, Tin, Cout, Tout, ks, stride, dil, pad, Mpad, act;
     float* y2; const float* alpha2;       // dual output (see ConvArgs::y2)
+    const float* dsn_src; const float* dsn_alpha;   // dgrad epilogue (see ConvArgs::dsn_src)
 };
 
 hipError_t launch_weight_norm(const float* v, const float* g, float* w, int rows, int inner, hipStream_t s);
@@ -28,6 +29,9 @@ hipError_t launch_gelu(const float* x, float* y, size_t n, hipStream_t s);
 hipError_t launch_strided3d(const float* a, size_t asb, size_t asc, const float* b2, size_t bsb, size_t bsc,
                             float* y, size_t ysb, size_t ysc, int B, int C, int n, hipStream_t s);
 
+hipError_t launch_pack_conv1d_dgrad(const float* w, float* wp, int cin, int cout, int ks, int mpad, hipStream_t s);
+hipError_t launch_pack_convtr_dgrad(const float* w, float* wp, int cin, int cout, int ks, int mpad, hipStream_t s);
+hipError_t launch_mul_dtanh(const float* g, const float* y, float* out, size_t n, hipStream_t s);
 hipError_t launch_align_xcorr(const float* r, const float* e, int T, int max_shift, float* corr, int* scratch_valid,
                               int* best_shift, hipStream_t s);
 

@@ -81,6 +81,16 @@ class WNConv1d(nn.Module):
     def folded_weight(self) -> torch.Tensor:
         return ops.weight_norm(self.weight_v.detach(), self.weight_g.detach())
 
+    def packed_dgrad(self) -> torch.Tensor:
+        if not hasattr(self, "_packed_dg"):
+            self._packed_dg = _Packed()
+        return self._packed_dg.get((self.weight_g, self.weight_v), lambda: ops.pack_conv1d_dgrad(self.folded_weight()))
+
+    def dgrad(self, gy, tin, dsnake_src=None, dsnake_alpha=None, residual=None):
+        """Gradient w.r.t. this conv's input (length tin), times the derivative of the Snake in front of it."""
+        return ops.conv1d_dgrad(gy, self.packed_dgrad(), self.cin, tin, self.ks, 1, self.dilation, self.padding,
+                                dsnake_src=dsnake_src, dsnake_alpha=dsnake_alpha, residual=residual)
+
     def run(self, x, alpha_in=None, residual=None, alpha_out=None, tanh=False, alpha_dual=None):
         return ops.conv1d(x, self.packed(), self.cout, self.ks, bias=self.bias.detach(), stride=self.stride,
                           dil=self.dilation, pad=self.padding, alpha_in=alpha_in, residual=residual,
@@ -108,6 +118,16 @@ class WNConvTranspose1d(nn.Module):
         return self._packed.get((self.weight_g, self.weight_v),
                                 lambda: ops.pack_conv_transpose1d(
                                     ops.weight_norm(self.weight_v.detach(), self.weight_g.detach()), self.stride))
+
+    def packed_dgrad(self) -> torch.Tensor:
+        if not hasattr(self, "_packed_dg"):
+            self._packed_dg = _Packed()
+        return self._packed_dg.get((self.weight_g, self.weight_v), lambda: ops.pack_conv_transpose1d_dgrad(
+            ops.weight_norm(self.weight_v.detach(), self.weight_g.detach())))
+
+    def dgrad(self, gy, tin, dsnake_src=None, dsnake_alpha=None):
+        return ops.conv1d_dgrad(gy, self.packed_dgrad(), self.cin, tin, self.ks, self.stride, 1, self.padding,
+                                dsnake_src=dsnake_src, dsnake_alpha=dsnake_alpha)
 
     def run(self, x, alpha_in=None, alpha_out=None, alpha_dual=None):
         return ops.conv_transpose1d(x, self.packed(), self.cout, self.stride, self.padding, bias=self.bias.detach(),
@@ -234,8 +254,56 @@ class Decoder(nn.Module):
         layers += [Snake1d(out), WNConv1d(out, d_out, 7, padding=3), nn.Tanh()]
         self.model = nn.Sequential(*layers)
 
+    # ---- training config: gradient w.r.t. the input, weights frozen ---------------
     @torch.no_grad()
+    def forward_saving(self, z):
+        """Same arithmetic as forward(), but every Snake input (and the final tanh output) is kept for the backward."""
+        m = self.model
+        nblk = len(m) - 4
+        saved = {"z_len": z.shape[-1]}
+        h = m[0].run(z)
+        for i in range(1, nblk + 1):
+            blk = m[i].block
+            saved[f"b{i}.x"] = h
+            h = blk[1].run(h, alpha_in=blk[0].flat())
+            for j in (2, 3, 4):
+                ru = blk[j].block
+                t7 = ru[1].run(h, alpha_in=ru[0].flat())
+                saved[f"b{i}.r{j}.x"], saved[f"b{i}.r{j}.t7"] = h, t7
+                h = ru[3].run(t7, alpha_in=ru[2].flat(), residual=h)
+        saved["hl"] = h
+        y = m[nblk + 2].run(h, alpha_in=m[nblk + 1].flat(), tanh=True)
+        saved["y"] = y
+        return y, saved
+
+    @torch.no_grad()
+    def backward_input(self, saved, gy):
+        """dL/dz from dL/dy: the same MFMA conv kernels on flipped / transposed weight images, Snake and tanh
+        derivatives fused into their epilogues (83 GFLOP per segment, like the forward)."""
+        m = self.model
+        nblk = len(m) - 4
+        g = ops.mul_dtanh(gy, saved["y"])
+        g = m[nblk + 2].dgrad(g, saved["hl"].shape[-1], dsnake_src=saved["hl"], dsnake_alpha=m[nblk + 1].flat())
+        for i in range(nblk, 0, -1):
+            blk = m[i].block
+            for j in (4, 3, 2):
+                ru = blk[j].block
+                x, t7 = saved[f"b{i}.r{j}.x"], saved[f"b{i}.r{j}.t7"]
+                g1 = ru[3].dgrad(g, t7.shape[-1], dsnake_src=t7, dsnake_alpha=ru[2].flat())
+                g = ru[1].dgrad(g1, x.shape[-1], dsnake_src=x, dsnake_alpha=ru[0].flat(), residual=g)
+            xin = saved[f"b{i}.x"]
+            g = blk[1].dgrad(g, xin.shape[-1], dsnake_src=xin, dsnake_alpha=blk[0].flat())
+        return m[0].dgrad(g, saved["z_len"])
+
     def forward(self, z):
+        """Inference: the fused fast path.  With autograd enabled and z.requires_grad (the reference's training step,
+        Training/compare_dacvsproposal_5.py:322,393): saving forward + HIP backward w.r.t. z; weights stay frozen."""
+        if torch.is_grad_enabled() and z.requires_grad:
+            return _DecoderInputGrad.apply(z, self)
+        return self._forward_fast(z)
+
+    @torch.no_grad()
+    def _forward_fast(self, z):
         m = self.model
         nblk = len(m) - 4
         h = m[0].run(z, alpha_out=m[1].block[0].flat())
@@ -243,6 +311,18 @@ class Decoder(nn.Module):
             nxt = m[i + 1].block[0].flat() if i < nblk else m[nblk + 1].flat()
             h = m[i].run(h, alpha_next=nxt, pre_snaked=True)
         return m[nblk + 2].run(h, tanh=True)
+
+
+class _DecoderInputGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, dec):
+        y, saved = dec.forward_saving(z.detach())
+        ctx.dec, ctx.saved = dec, saved
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return ctx.dec.backward_input(ctx.saved, gy.contiguous()), None
 
 
 class VectorQuantize(nn.Module):

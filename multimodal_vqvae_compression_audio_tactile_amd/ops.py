@@ -281,3 +281,42 @@ def align_xcorr(ref, est, max_shift=200):
     check(_lib.lib().mvq_align_xcorr_f32(ref.data_ptr(), est.data_ptr(), ref.numel(), max_shift, corr.data_ptr(),
                                          scratch.data_ptr(), best.data_ptr(), _stream()), "mvq_align_xcorr_f32")
     return corr, best
+
+
+# ---------------------------------------------------------------------------------- backward (row f1)
+def pack_conv1d_dgrad(w: torch.Tensor) -> torch.Tensor:
+    """Conv1d weight w[Cout,Cin,ks] -> packed image of its input-gradient conv (flip + transpose)."""
+    w = _dev(w, "w")
+    cout, cin, ks = w.shape
+    wp = torch.empty(_lib.lib().mvq_conv1d_dgrad_packed_floats(cin, cout, ks), device=w.device, dtype=torch.float32)
+    check(_lib.lib().mvq_conv1d_pack_dgrad_f32(w.data_ptr(), wp.data_ptr(), cin, cout, ks, _stream()),
+          "mvq_conv1d_pack_dgrad_f32")
+    return wp
+
+
+def pack_conv_transpose1d_dgrad(w: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose1d weight w[Cin,Cout,ks] -> packed image of its input-gradient (a strided conv)."""
+    w = _dev(w, "w")
+    cin, cout, ks = w.shape
+    wp = torch.empty(_lib.lib().mvq_conv1d_dgrad_packed_floats(cin, cout, ks), device=w.device, dtype=torch.float32)
+    check(_lib.lib().mvq_conv_transpose1d_pack_dgrad_f32(w.data_ptr(), wp.data_ptr(), cin, cout, ks, _stream()),
+          "mvq_conv_transpose1d_pack_dgrad_f32")
+    return wp
+
+
+def conv1d_dgrad(gy, wp_dgrad, cin, tin, ks, stride=1, dil=1, pad=0, dsnake_src=None, dsnake_alpha=None, residual=None):
+    """gx[B,cin,tin] = dgrad-conv(gy) * dsnake(dsnake_src) + residual; layer described by its FORWARD geometry."""
+    gy = _dev(gy, "gy")
+    B, cout, tout = gy.shape
+    gx = torch.empty(B, cin, tin, device=gy.device, dtype=torch.float32)
+    check(_lib.lib().mvq_conv1d_dgrad_f32(gy.data_ptr(), wp_dgrad.data_ptr(), _p(dsnake_src), _p(dsnake_alpha),
+                                          _p(residual), gx.data_ptr(), B, cin, tin, cout, tout, ks, stride, dil, pad,
+                                          _stream()), "mvq_conv1d_dgrad_f32")
+    return gx
+
+
+def mul_dtanh(g, y):
+    g = _dev(g, "g"); y = _dev(y, "y")
+    out = torch.empty_like(g)
+    check(_lib.lib().mvq_mul_dtanh_f32(g.data_ptr(), y.data_ptr(), out.data_ptr(), g.numel(), _stream()), "mvq_mul_dtanh_f32")
+    return out

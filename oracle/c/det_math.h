@@ -152,4 +152,12 @@ static inline float om_snake(float x, float alpha)
     return om_fma(inv, om_sin2(alpha * x), x);
 }
 
+/* d snake(x)/dx = 1 + (alpha/(alpha+1e-9)) * sin(2*alpha*x)   (backward of Snake1d) */
+static inline float om_dsnake(float x, float alpha)
+{
+    float inv = 1.0f / (alpha + 1e-9f);
+    float ax = alpha * x;
+    return om_fma(alpha * inv, om_sin(ax + ax), 1.0f);
+}
+
 #endif /* ORACLE_DET_MATH_H */

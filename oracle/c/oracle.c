@@ -504,3 +504,30 @@ int orc_align_xcorr(const float* r, const float* e, int T, int max_shift, float*
     }
     return best_s;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward pieces (decoder input-gradient, weights frozen).
+ *   orc_mul_dsnake : g[b,c,t] *= d snake(x[b,c,t])/dx  (+ residual), the Snake1d backward fused behind a dgrad conv
+ *   orc_mul_dtanh  : g *= (1 - y^2)                                   (decoder tail tanh)
+ * The dgrad convs themselves are orc_conv1d with flipped / transposed weights (see oracle.py).
+ * ---------------------------------------------------------------------------------------------- */
+void orc_mul_dsnake(const float* g, const float* x, const float* alpha, const float* residual, float* out,
+                    int B, int C, int T)
+{
+#pragma omp parallel for collapse(2)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            size_t o = ((size_t)b * C + c) * T;
+            float a = alpha[c];
+            for (int t = 0; t < T; ++t) {
+                float v = g[o + t] * om_dsnake(x[o + t], a);
+                if (residual) v = v + residual[o + t];
+                out[o + t] = v;
+            }
+        }
+}
+
+void orc_mul_dtanh(const float* g, const float* y, float* out, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) out[i] = g[i] * om_fma(-y[i], y[i], 1.0f);
+}

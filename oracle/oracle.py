@@ -419,3 +419,82 @@ def align_by_xcorr(ref_1T, est_1T, max_shift=200):
     else:
         r_a, e_a = r_, e_[:r_.size]
     return r_a[None], e_a[None], int(s), corr
+
+
+# ------------------------------------------------------------------------------------- backward (row f1)
+def mul_dsnake(g, x, alpha, residual=None):
+    g_, gp = _f(g); x_, xp = _f(x); a_, ap = _f(np.reshape(alpha, -1))
+    r_, rp = _opt(residual)
+    out = np.empty_like(g_)
+    B, C, T = g_.shape
+    lib().orc_mul_dsnake(gp, xp, ap, rp, out.ctypes.data_as(f32p), B, C, T)
+    return out
+
+
+def mul_dtanh(g, y):
+    g_, gp = _f(g); y_, yp = _f(y)
+    out = np.empty_like(g_)
+    fn = lib().orc_mul_dtanh
+    fn.argtypes = [f32p, f32p, f32p, ctypes.c_size_t]
+    fn(gp, yp, out.ctypes.data_as(f32p), g_.size)
+    return out
+
+
+def conv1d_dgrad(gy, w, dil=1, pad=0):
+    """Input-gradient of y = conv1d(x, w[Cout,Cin,k], stride 1): conv1d(gy, w'), w'[ci,co,k] = w[co,ci,K-1-k];
+    chain order = forward output channel, then tap (what orc_conv1d does with w')."""
+    w = np.asarray(w, np.float32)
+    wt = np.ascontiguousarray(w[:, :, ::-1].transpose(1, 0, 2))
+    return conv1d(gy, wt, None, 1, dil, (w.shape[2] - 1) * dil - pad)
+
+
+def conv_transpose1d_dgrad(gy, w, stride, pad):
+    """Input-gradient of y = conv_transpose1d(x, w[Cin,Cout,k]): conv1d(gy, w viewed as [out=Cin, in=Cout, k], stride, pad)."""
+    return conv1d(gy, np.ascontiguousarray(w, np.float32), None, stride, 1, pad)
+
+
+def dac_decoder_saving(sd, z, rates=DEC_RATES, prefix=""):
+    """Decoder forward that keeps every Snake input (same values as dac_decoder)."""
+    P = prefix
+    saved = {}
+    w, b = _wn(sd, P + "model.0")
+    h = conv1d(z, w, b, pad=3)
+    for i, s in enumerate(rates):
+        p = f"{P}model.{i + 1}"
+        saved[f"b{i + 1}.x"] = h
+        w, b = _wn(sd, p + ".block.1")
+        h = conv_transpose1d(h, w, b, stride=s, pad=math.ceil(s / 2), alpha_in=sd[p + ".block.0.alpha"])
+        for j, dil in enumerate((1, 3, 9)):
+            q = f"{p}.block.{j + 2}"
+            w7, b7 = _wn(sd, q + ".block.1"); w1, b1 = _wn(sd, q + ".block.3")
+            t7 = conv1d(h, w7, b7, dil=dil, pad=3 * dil, alpha_in=sd[q + ".block.0.alpha"])
+            saved[f"b{i + 1}.r{j + 2}.x"], saved[f"b{i + 1}.r{j + 2}.t7"] = h, t7
+            h = conv1d(t7, w1, b1, alpha_in=sd[q + ".block.2.alpha"], residual=h)
+    n = len(rates) + 1
+    saved["hl"] = h
+    w, b = _wn(sd, f"{P}model.{n + 1}")
+    y = conv1d(h, w, b, pad=3, alpha_in=sd[f"{P}model.{n}.alpha"], tanh=True)
+    saved["y"] = y
+    return y, saved
+
+
+def dac_decoder_backward_input(sd, saved, gy, rates=DEC_RATES, prefix=""):
+    """dL/dz of the decoder (weights frozen): mirrors Decoder.backward_input of the product path."""
+    P = prefix
+    n = len(rates) + 1
+    g = mul_dtanh(gy, saved["y"])
+    w, _ = _wn(sd, f"{P}model.{n + 1}")
+    g = mul_dsnake(conv1d_dgrad(g, w, 1, 3), saved["hl"], sd[f"{P}model.{n}.alpha"])
+    for i in range(len(rates), 0, -1):
+        p = f"{P}model.{i}"
+        s = rates[i - 1]
+        for j, dil in reversed(list(enumerate((1, 3, 9)))):
+            q = f"{p}.block.{j + 2}"
+            w7, _ = _wn(sd, q + ".block.1"); w1, _ = _wn(sd, q + ".block.3")
+            x, t7 = saved[f"b{i}.r{j + 2}.x"], saved[f"b{i}.r{j + 2}.t7"]
+            g1 = mul_dsnake(conv1d_dgrad(g, w1, 1, 0), t7, sd[q + ".block.2.alpha"])
+            g = mul_dsnake(conv1d_dgrad(g1, w7, dil, 3 * dil), x, sd[q + ".block.0.alpha"], residual=g)
+        w, _ = _wn(sd, p + ".block.1")
+        g = mul_dsnake(conv_transpose1d_dgrad(g, w, s, math.ceil(s / 2)), saved[f"b{i}.x"], sd[p + ".block.0.alpha"])
+    w, _ = _wn(sd, P + "model.0")
+    return conv1d_dgrad(g, w, 1, 3)
