@@ -3,6 +3,8 @@
 namespace mvq {
 hipError_t launch_conv_strided(const ConvArgs& a, int stride, int bm, hipStream_t s)
 {
+    // 96-row tiles: only the input-gradient of the last DecoderBlock's ConvTranspose1d (96 <- 192 channels, stride 2)
+    if (bm == 96 && stride == 2) return launch_conv1d_mfma<4, 2, 1, 16, 3, 1, 1, 4, 0>(a, s);
     if (bm != 128) return hipErrorInvalidValue;
     if (conv_prefer_small_tiles(a)) {
         switch (stride) {

@@ -121,11 +121,29 @@ __device__ __forceinline__ float det_snake(float x, float alpha, float inv_alpha
     return dfma(inv_alpha, det_sin2(alpha * x), x);
 }
 
+// sin(y) with the period-pi reduction of det_sin2: one odd polynomial, sign from the parity of n
+__device__ __forceinline__ float det_sin_pi(float y)
+{
+    const float n = __builtin_rintf(y * 0.318309886183790672f);
+    float r = dfma(-n, 3.140625f, y);
+    r = dfma(-n, 9.67502593994140625e-4f, r);
+    r = dfma(-n, 1.509957990978376e-7f, r);
+    const float u = r * r;
+    float p = dfma(u, -7.64716373e-13f, 1.60590438e-10f);
+    p = dfma(u, p, -2.50521084e-08f);
+    p = dfma(u, p, 2.75573192e-06f);
+    p = dfma(u, p, -1.98412698e-04f);
+    p = dfma(u, p, 8.33333333e-03f);
+    p = dfma(u, p, -1.66666667e-01f);
+    const float s = dfma(r * u, p, r);
+    return ((int)n & 1) ? -s : s;
+}
+
 // d snake(x)/dx = 1 + (alpha/(alpha+1e-9)) * sin(2*alpha*x)   (backward of Snake1d)
 __device__ __forceinline__ float det_dsnake(float x, float alpha, float inv_alpha)
 {
     const float ax = alpha * x;
-    return dfma(alpha * inv_alpha, det_sin(ax + ax), 1.0f);
+    return dfma(alpha * inv_alpha, det_sin_pi(ax + ax), 1.0f);
 }
 
 }  // namespace mvq

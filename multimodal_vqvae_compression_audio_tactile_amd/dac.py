@@ -261,18 +261,20 @@ class Decoder(nn.Module):
         m = self.model
         nblk = len(m) - 4
         saved = {"z_len": z.shape[-1]}
-        h = m[0].run(z)
+        # every producer emits (raw, Snake for the consumer): no conv evaluates Snake while staging
+        h, hs = m[0].run(z, alpha_dual=m[1].block[0].flat())
         for i in range(1, nblk + 1):
             blk = m[i].block
             saved[f"b{i}.x"] = h
-            h = blk[1].run(h, alpha_in=blk[0].flat())
+            h, hs = blk[1].run(hs, alpha_dual=blk[2].block[0].flat())
             for j in (2, 3, 4):
                 ru = blk[j].block
-                t7 = ru[1].run(h, alpha_in=ru[0].flat())
+                t7, t7s = ru[1].run(hs, alpha_dual=ru[2].flat())
                 saved[f"b{i}.r{j}.x"], saved[f"b{i}.r{j}.t7"] = h, t7
-                h = ru[3].run(t7, alpha_in=ru[2].flat(), residual=h)
+                nxt = blk[j + 1].block[0].flat() if j < 4 else (m[i + 1].block[0].flat() if i < nblk else m[nblk + 1].flat())
+                h, hs = ru[3].run(t7s, residual=h, alpha_dual=nxt)
         saved["hl"] = h
-        y = m[nblk + 2].run(h, alpha_in=m[nblk + 1].flat(), tanh=True)
+        y = m[nblk + 2].run(hs, tanh=True)
         saved["y"] = y
         return y, saved
 

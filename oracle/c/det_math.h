@@ -152,12 +152,31 @@ static inline float om_snake(float x, float alpha)
     return om_fma(inv, om_sin2(alpha * x), x);
 }
 
+/* sin(y) with the period-pi reduction of om_sin2: n = rint(y/pi), r = y - n*pi in [-pi/2, pi/2],
+ * sin(y) = (-1)^n * (r - r^3/3! + ... - r^15/15!)   (one odd polynomial, sign from the parity of n) */
+static inline float om_sin_pi(float y)
+{
+    float n = rintf(y * 0.318309886183790672f);
+    float r = om_fma(-n, 3.140625f, y);
+    r = om_fma(-n, 9.67502593994140625e-4f, r);
+    r = om_fma(-n, 1.509957990978376e-7f, r);
+    float u = r * r;
+    float p = om_fma(u, -7.64716373e-13f, 1.60590438e-10f);
+    p = om_fma(u, p, -2.50521084e-08f);
+    p = om_fma(u, p, 2.75573192e-06f);
+    p = om_fma(u, p, -1.98412698e-04f);
+    p = om_fma(u, p, 8.33333333e-03f);
+    p = om_fma(u, p, -1.66666667e-01f);
+    float s = om_fma(r * u, p, r);
+    return ((int)n & 1) ? -s : s;
+}
+
 /* d snake(x)/dx = 1 + (alpha/(alpha+1e-9)) * sin(2*alpha*x)   (backward of Snake1d) */
 static inline float om_dsnake(float x, float alpha)
 {
     float inv = 1.0f / (alpha + 1e-9f);
     float ax = alpha * x;
-    return om_fma(alpha * inv, om_sin(ax + ax), 1.0f);
+    return om_fma(alpha * inv, om_sin_pi(ax + ax), 1.0f);
 }
 
 #endif /* ORACLE_DET_MATH_H */

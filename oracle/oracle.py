@@ -135,6 +135,7 @@ def gelu(x): return _unary("orc_gelu", x)
 def tanh(x): return _unary("orc_tanh", x)
 def sin(x): return _unary("orc_sin", x)
 def sin2(x): return _unary("orc_sin2", x)
+def sin_pi(x): return _unary("orc_sin_pi", x)
 def exp(x): return _unary("orc_exp", x)
 def erf(x): return _unary("orc_erf", x)
 

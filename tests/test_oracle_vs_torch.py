@@ -14,6 +14,7 @@ def test_det_math_accuracy(orc):
     assert np.abs(orc.sin(x) - np.sin(x.astype(np.float64))).max() < 1.5e-7
     x = r.uniform(-200, 200, 400000).astype(np.float32)
     assert np.abs(orc.sin2(x) - np.sin(x.astype(np.float64)) ** 2).max() < 2.5e-7       # Snake's sin^2 (period-pi form)
+    assert np.abs(orc.sin_pi(x) - np.sin(x.astype(np.float64))).max() < 2.5e-7            # Snake backward's sin
     xs = r.uniform(-3, 3, 100000).astype(np.float32)
     assert np.abs(orc.sin2(xs) - np.sin(xs.astype(np.float64)) ** 2).max() < 2.5e-7
     x = r.uniform(-87, 20, 400000).astype(np.float32)

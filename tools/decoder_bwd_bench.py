@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Decoder forward(saving) + backward-input timing (training config building block).  usage: decoder_bwd_bench.py [B]"""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+import multimodal_vqvae_compression_audio_tactile_amd as mvq
+from multimodal_vqvae_compression_audio_tactile_amd import synth
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+dev = torch.device("cuda:0")
+dec = mvq.Decoder(); dec.load_state_dict(synth.decoder_state(74), strict=True); dec = dec.to(dev)
+z = 0.3 * torch.randn(B, 1024, 75, device=dev)
+def t(fn, n=3):
+    fn(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): out = fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n, out
+ms_f, _ = t(lambda: dec._forward_fast(z))
+ms_s, (y, saved) = t(lambda: dec.forward_saving(z))
+gy = torch.randn_like(y)
+ms_b, gz = t(lambda: dec.backward_input(saved, gy))
+gf = 83.41 * B
+print(f"B={B}: inference forward {ms_f:.1f} ms ({gf/ms_f:.1f} TF) | saving forward {ms_s:.1f} ms ({gf/ms_s:.1f} TF) | backward-input {ms_b:.1f} ms ({gf/ms_b:.1f} TF)")
