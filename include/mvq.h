@@ -205,6 +205,31 @@ int mvq_conv1d_dgrad_f32(const float* gy, const float* wp_dgrad, const float* ds
                          int batch, int cin, int tin, int cout, int tout, int ks, int stride, int dil, int pad,
                          void* stream);
 
+/* Backward of the reference's own trainable modules (CrossPredictor, TokenNorm, tanh*scale; Training/
+ * compare_dacvsproposal_5.py:222-244,313-315 under `scaler.scale(total).backward()`, ...:393).  Same addressing as the
+ * forward entry points.  Checked against torch autograd (fp32 tolerance), not part of the bit-exact forward contract.
+ *   layernorm_c_bwd : gx (may be NULL) and dgamma/dbeta (ACCUMULATED into) from g; stats[2*B*T] scratch (mu, rstd)
+ *   gelu_bwd        : gx = g * gelu'(x)
+ *   scale_tanh      : y = scale * tanh(u);  _bwd: gu = g*scale*(1-tanh(u)^2), partial[n_partial] block sums of g*tanh(u)
+ *                     (their total is d/dscale), n_partial <= 4096
+ *   attention_bwd   : gq, gk, gv from g = dL/dctx (Tq, Tk <= 32)
+ *   mul_scaled      : out = a*b*scale (nn.Dropout on ctx, ...:242: the keep-mask is drawn by the caller; also its backward)
+ *   transpose2d     : out[c][r] = in[r][c]      rowsum: out[r] (+)= sum_c in[r][c]   (weight / bias gradients: the
+ *                     weight gradient dW = g x^T over the token axis runs on mvq_conv1d_f32 with K = tokens) */
+int mvq_layernorm_c_bwd_f32(const float* x, const float* pe, const float* gamma, const float* g, float* gx,
+                            float* dgamma, float* dbeta, float* stats, int batch, int c, int t,
+                            size_t stride_b, size_t stride_c, float eps, void* stream);
+int mvq_gelu_bwd_f32(const float* x, const float* g, float* gx, size_t n, void* stream);
+int mvq_scale_tanh_f32(const float* u, float scale, float* y, size_t n, void* stream);
+int mvq_scale_tanh_bwd_f32(const float* u, const float* g, float scale, float* gu, float* partial, int n_partial, size_t n,
+                           void* stream);
+int mvq_attention_bwd_f32(const float* q, const float* k, const float* v, const float* g, float* gq, float* gk, float* gv,
+                          int batch, int heads, int dh, int tq, int tk,
+                          size_t q_stride_b, size_t q_stride_c, size_t k_stride_b, size_t k_stride_c, void* stream);
+int mvq_mul_scaled_f32(const float* a, const float* b, float scale, float* out, size_t n, void* stream);
+int mvq_transpose2d_f32(const float* in, float* out, int rows, int cols, void* stream);
+int mvq_rowsum_f32(const float* in, float* out, int rows, int cols, int accumulate, void* stream);
+
 /* out = g * (1 - y*y): backward of the decoder's final tanh (y = saved output). */
 int mvq_mul_dtanh_f32(const float* g, const float* y, float* out, size_t n, void* stream);
 

@@ -45,6 +45,14 @@ EXPORTS = {
     "mvq_conv_transpose1d_pack_dgrad_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mvq_conv1d_dgrad_f32": (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p]),
     "mvq_mul_dtanh_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mvq_layernorm_c_bwd_f32": (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_size_t] * 2 + [c_float, c_void_p]),
+    "mvq_gelu_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mvq_scale_tanh_f32": (c_int, [c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "mvq_scale_tanh_bwd_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    "mvq_attention_bwd_f32": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_size_t] * 4 + [c_void_p]),
+    "mvq_mul_scaled_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "mvq_transpose2d_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mvq_rowsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mvq_gelu_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvq_sub3d_f32": (c_int, [c_void_p, c_size_t, c_size_t] * 3 + [c_int] * 3 + [c_void_p]),
     "mvq_copy3d_f32": (c_int, [c_void_p, c_size_t, c_size_t] * 2 + [c_int] * 3 + [c_void_p]),

@@ -421,6 +421,78 @@ int mvq_conv1d_dgrad_f32(const float* gy, const float* wp_dgrad, const float* ds
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_dgrad");
 }
 
+/* backward of the reference-owned trainable modules (tolerance-checked against torch autograd) */
+int mvq_layernorm_c_bwd_f32(const float* x, const float* pe, const float* gamma, const float* g, float* gx,
+                            float* dgamma, float* dbeta, float* stats, int batch, int c, int t,
+                            size_t stride_b, size_t stride_c, float eps, void* stream)
+{
+    if (c <= 0 || batch < 0 || t < 0) return fail(MVQ_EINVAL, "layernorm_c_bwd: bad shape");
+    if (batch == 0 || t == 0) return MVQ_OK;
+    if (!x || !gamma || !g || !dgamma || !dbeta || !stats) return fail(MVQ_EINVAL, "layernorm_c_bwd: null tensor");
+    if (stride_b == 0 && stride_c == 0) { stride_b = (size_t)c * t; stride_c = (size_t)t; }
+    hipError_t e = mvq::launch_layernorm_bwd(x, pe, gamma, g, gx, dgamma, dbeta, stats, batch, c, t, stride_b, stride_c, eps, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "layernorm_c_bwd");
+}
+
+int mvq_gelu_bwd_f32(const float* x, const float* g, float* gx, size_t n, void* stream)
+{
+    if ((!x || !g || !gx) && n) return fail(MVQ_EINVAL, "gelu_bwd: null tensor");
+    hipError_t e = mvq::launch_gelu_bwd(x, g, gx, n, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "gelu_bwd");
+}
+
+int mvq_scale_tanh_f32(const float* u, float scale, float* y, size_t n, void* stream)
+{
+    if ((!u || !y) && n) return fail(MVQ_EINVAL, "scale_tanh: null tensor");
+    hipError_t e = mvq::launch_scale_tanh(u, scale, y, n, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "scale_tanh");
+}
+
+int mvq_scale_tanh_bwd_f32(const float* u, const float* g, float scale, float* gu, float* partial, int n_partial, size_t n,
+                           void* stream)
+{
+    if (((!u || !g || !gu) && n) || !partial || n_partial <= 0 || n_partial > 4096) return fail(MVQ_EINVAL, "scale_tanh_bwd: bad argument");
+    hipError_t e = mvq::launch_scale_tanh_bwd(u, g, scale, gu, partial, n_partial, n, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "scale_tanh_bwd");
+}
+
+int mvq_attention_bwd_f32(const float* q, const float* k, const float* v, const float* g, float* gq, float* gk, float* gv,
+                          int batch, int heads, int dh, int tq, int tk,
+                          size_t q_stride_b, size_t q_stride_c, size_t k_stride_b, size_t k_stride_c, void* stream)
+{
+    if (batch < 0 || heads <= 0 || dh <= 0 || tq < 0 || tk < 0 || tq > 32 || tk > 32) return fail(MVQ_EINVAL, "attention_bwd: bad shape (Tq, Tk <= 32)");
+    if (batch == 0 || tq == 0) return MVQ_OK;
+    if (!q || !g || !gq || (tk > 0 && (!k || !v || !gk || !gv))) return fail(MVQ_EINVAL, "attention_bwd: null tensor");
+    const size_t c = (size_t)heads * dh;
+    if (q_stride_b == 0 && q_stride_c == 0) { q_stride_b = c * tq; q_stride_c = (size_t)tq; }
+    if (k_stride_b == 0 && k_stride_c == 0) { k_stride_b = c * tk; k_stride_c = (size_t)tk; }
+    hipError_t e = mvq::launch_attention_bwd(q, k, v, g, gq, gk, gv, batch, heads, dh, tq, tk, q_stride_b, q_stride_c, k_stride_b, k_stride_c, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "attention_bwd");
+}
+
+int mvq_mul_scaled_f32(const float* a, const float* b, float scale, float* out, size_t n, void* stream)
+{
+    if ((!a || !b || !out) && n) return fail(MVQ_EINVAL, "mul_scaled: null tensor");
+    hipError_t e = mvq::launch_mul_scaled(a, b, scale, out, n, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "mul_scaled");
+}
+
+int mvq_transpose2d_f32(const float* in, float* out, int rows, int cols, void* stream)
+{
+    if (rows < 0 || cols < 0) return fail(MVQ_EINVAL, "transpose2d: bad shape");
+    if ((!in || !out) && rows && cols) return fail(MVQ_EINVAL, "transpose2d: null tensor");
+    hipError_t e = mvq::launch_transpose2d(in, out, rows, cols, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "transpose2d");
+}
+
+int mvq_rowsum_f32(const float* in, float* out, int rows, int cols, int accumulate, void* stream)
+{
+    if (rows < 0 || cols < 0) return fail(MVQ_EINVAL, "rowsum: bad shape");
+    if ((!in || !out) && rows) return fail(MVQ_EINVAL, "rowsum: null tensor");
+    hipError_t e = mvq::launch_rowsum(in, out, rows, cols, accumulate, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "rowsum");
+}
+
 int mvq_mul_dtanh_f32(const float* g, const float* y, float* out, size_t n, void* stream)
 {
     if ((!g || !y || !out) && n) return fail(MVQ_EINVAL, "mul_dtanh: null tensor");

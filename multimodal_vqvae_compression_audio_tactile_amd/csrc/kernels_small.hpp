@@ -32,6 +32,18 @@ hipError_t launch_strided3d(const float* a, size_t asb, size_t asc, const float*
 hipError_t launch_pack_conv1d_dgrad(const float* w, float* wp, int cin, int cout, int ks, int mpad, hipStream_t s);
 hipError_t launch_pack_convtr_dgrad(const float* w, float* wp, int cin, int cout, int ks, int mpad, hipStream_t s);
 hipError_t launch_mul_dtanh(const float* g, const float* y, float* out, size_t n, hipStream_t s);
+hipError_t launch_layernorm_bwd(const float* x, const float* pe, const float* gamma, const float* g, float* gx,
+                                float* dgamma, float* dbeta, float* stats, int B, int C, int T, size_t sb, size_t sc,
+                                float eps, hipStream_t s);
+hipError_t launch_gelu_bwd(const float* x, const float* g, float* gx, size_t n, hipStream_t s);
+hipError_t launch_scale_tanh(const float* u, float s, float* y, size_t n, hipStream_t st);
+hipError_t launch_scale_tanh_bwd(const float* u, const float* g, float s, float* gu, float* partial, int n_partial, size_t n,
+                                 hipStream_t st);
+hipError_t launch_attention_bwd(const float* q, const float* k, const float* v, const float* g, float* gq, float* gk, float* gv,
+                                int B, int H, int dh, int Tq, int Tk, size_t qsb, size_t qsc, size_t ksb, size_t ksc, hipStream_t s);
+hipError_t launch_mul_scaled(const float* a, const float* b, float scale, float* out, size_t n, hipStream_t s);
+hipError_t launch_transpose2d(const float* in, float* out, int rows, int cols, hipStream_t s);
+hipError_t launch_rowsum(const float* in, float* out, int rows, int cols, int accumulate, hipStream_t s);
 hipError_t launch_align_xcorr(const float* r, const float* e, int T, int max_shift, float* corr, int* scratch_valid,
                               int* best_shift, hipStream_t s);
 

@@ -320,3 +320,111 @@ def mul_dtanh(g, y):
     out = torch.empty_like(g)
     check(_lib.lib().mvq_mul_dtanh_f32(g.data_ptr(), y.data_ptr(), out.data_ptr(), g.numel(), _stream()), "mvq_mul_dtanh_f32")
     return out
+
+
+# ------------------------------------------------------- backward of the reference-owned trainable modules (row f1)
+def _fold_dims(x, folded_batch):
+    B, C, T = x.shape
+    if folded_batch is None:
+        return B, C, T, 0, 0
+    if B != 1 or T % folded_batch:
+        raise MvqError("folded tensor must be [1, C, B*T]")
+    T //= folded_batch
+    return folded_batch, C, T, T, folded_batch * T
+
+
+def layernorm_c_bwd(x, gamma, g, pe=None, eps=1e-5, folded_batch=None, need_gx=True):
+    """-> (gx or None, dgamma, dbeta) for y = LayerNorm_C(x + pe)."""
+    x = _dev(x, "x"); g = _dev(g, "g")
+    B, C, T, sb, sc = _fold_dims(x, folded_batch)
+    gx = torch.empty_like(x) if need_gx else None
+    dgamma = torch.zeros(C, device=x.device, dtype=torch.float32)
+    dbeta = torch.zeros(C, device=x.device, dtype=torch.float32)
+    stats = torch.empty(2 * max(B * T, 1), device=x.device, dtype=torch.float32)
+    check(_lib.lib().mvq_layernorm_c_bwd_f32(x.data_ptr(), _p(pe), gamma.data_ptr(), g.data_ptr(), _p(gx),
+                                             dgamma.data_ptr(), dbeta.data_ptr(), stats.data_ptr(), B, C, T, sb, sc,
+                                             float(eps), _stream()), "mvq_layernorm_c_bwd_f32")
+    return gx, dgamma, dbeta
+
+
+def gelu_bwd(x, g):
+    x = _dev(x, "x"); g = _dev(g, "g")
+    gx = torch.empty_like(x)
+    check(_lib.lib().mvq_gelu_bwd_f32(x.data_ptr(), g.data_ptr(), gx.data_ptr(), x.numel(), _stream()), "mvq_gelu_bwd_f32")
+    return gx
+
+
+def scale_tanh(u, scale: float):
+    u = _dev(u, "u")
+    y = torch.empty_like(u)
+    check(_lib.lib().mvq_scale_tanh_f32(u.data_ptr(), float(scale), y.data_ptr(), u.numel(), _stream()), "mvq_scale_tanh_f32")
+    return y
+
+
+def scale_tanh_bwd(u, g, scale: float):
+    """-> (gu, d/dscale as a 0-d device tensor)."""
+    u = _dev(u, "u"); g = _dev(g, "g")
+    gu = torch.empty_like(u)
+    nblk = max(1, min(1024, (u.numel() + 255) // 256))
+    partial = torch.zeros(nblk, device=u.device, dtype=torch.float32)
+    check(_lib.lib().mvq_scale_tanh_bwd_f32(u.data_ptr(), g.data_ptr(), float(scale), gu.data_ptr(), partial.data_ptr(),
+                                            nblk, u.numel(), _stream()), "mvq_scale_tanh_bwd_f32")
+    dscale = torch.empty(1, device=u.device, dtype=torch.float32)
+    check(_lib.lib().mvq_rowsum_f32(partial.data_ptr(), dscale.data_ptr(), 1, nblk, 0, _stream()), "mvq_rowsum_f32")
+    return gu, dscale.reshape(())
+
+
+def attention_bwd(q, k, v, g, heads, folded_batch=None):
+    q = _dev(q, "q"); k = _dev(k, "k"); v = _dev(v, "v"); g = _dev(g, "g")
+    B, C, Tq = q.shape
+    Tk = k.shape[2]
+    strides = (0, 0, 0, 0)
+    if folded_batch is not None:
+        B = folded_batch
+        Tq, Tk = Tq // B, Tk // B
+        strides = (Tq, B * Tq, Tk, B * Tk)
+    gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    check(_lib.lib().mvq_attention_bwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), g.data_ptr(), gq.data_ptr(),
+                                           gk.data_ptr(), gv.data_ptr(), B, heads, C // heads, Tq, Tk, *strides,
+                                           _stream()), "mvq_attention_bwd_f32")
+    return gq, gk, gv
+
+
+def mul_scaled(a, b, scale=1.0):
+    a = _dev(a, "a"); b = _dev(b, "b")
+    out = torch.empty_like(a)
+    check(_lib.lib().mvq_mul_scaled_f32(a.data_ptr(), b.data_ptr(), float(scale), out.data_ptr(), a.numel(), _stream()),
+          "mvq_mul_scaled_f32")
+    return out
+
+
+def transpose2d(x):
+    x = _dev(x, "x")
+    r, c = x.shape
+    out = torch.empty(c, r, device=x.device, dtype=torch.float32)
+    check(_lib.lib().mvq_transpose2d_f32(x.data_ptr(), out.data_ptr(), r, c, _stream()), "mvq_transpose2d_f32")
+    return out
+
+
+def rowsum(x):
+    x = _dev(x, "x")
+    r, c = x.shape
+    out = torch.empty(r, device=x.device, dtype=torch.float32)
+    check(_lib.lib().mvq_rowsum_f32(x.data_ptr(), out.data_ptr(), r, c, 0, _stream()), "mvq_rowsum_f32")
+    return out
+
+
+def linear_wgrad(g, x):
+    """dW[O,I] = g[O,N] x[I,N]^T over the token axis N, as a k=1 conv on the MFMA kernel with K = tokens:
+    packed 'weights' = g^T (K-major), input = x^T [N, I].  N is padded with zero tokens to a multiple of 8."""
+    g = _dev(g, "g"); x = _dev(x, "x")
+    O, N = g.shape
+    I, N2 = x.shape
+    if N != N2:
+        raise MvqError("linear_wgrad: token counts differ")
+    if N % 8:
+        padn = 8 - N % 8
+        g = torch.nn.functional.pad(g, (0, padn)); x = torch.nn.functional.pad(x, (0, padn)); N += padn
+    wp = pack_conv1d(g.reshape(O, N, 1))
+    xt = transpose2d(x).reshape(1, N, I)
+    return conv1d(xt, wp, O, 1).reshape(O, I)

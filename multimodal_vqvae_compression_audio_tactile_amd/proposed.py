@@ -12,7 +12,9 @@ MI355X-first differences that do not change results:
     residual adds into GEMM epilogues;
   * the shift-by-one input ``zt_prev`` is built exactly as the reference does (only column 0 of a chunk with
     s > 0 is non-zero -- SURVEY.md section 3.1 "Observed data dependency").
-Dropout is the identity here (eval semantics); train-mode dropout / backward are not part of this round.
+Training (row f1 of SURVEY.md section 8): with autograd enabled, ``AllPredAR.forward_step`` builds the graph out of the
+HIP-backed autograd Functions in train.py (same forward kernels, HIP backward kernels), so the reference's
+``total.backward(); opt.step()`` works on these modules unchanged; ``net.train()`` enables the ctx dropout.
 """
 from __future__ import annotations
 
@@ -22,7 +24,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, train
 from ._lib import MvqError
 from .dac import _Packed
 
@@ -101,9 +103,29 @@ class CrossPredictor(nn.Module):
         hdn = ops.gelu(L["f1"](hdn))
         return L["f3"](hdn, residual=y1)                                    # ffn(y) + y
 
-    def forward(self, zt_prev, za):
+    def run_train(self, zt_prev, za, folded_batch):
+        """Same computation as run() on token-folded tensors, recorded for autograd (train.py Functions)."""
+        fb, pe, L = folded_batch, self.pos.pe, self._lin
+        lin = lambda n, mod, x, res=None: train.Linear.apply(x, mod.weight, getattr(mod, "bias", None), res, L[n])
+        q = train.LayerNormC.apply(zt_prev, self.ln_q.weight, self.ln_q.bias, pe, self.ln_q.eps, fb)
+        kv = train.LayerNormC.apply(za, self.ln_kv.weight, self.ln_kv.bias, pe, self.ln_kv.eps, fb)
+        Q, K, V = lin("q", self.q_proj, q), lin("k", self.k_proj, kv), lin("v", self.v_proj, kv)
+        ctx = train.Attention.apply(Q, K, V, self.h, fb)
         if self.training and self.drop.p > 0:
-            raise MvqError("CrossPredictor: train-mode dropout is outside this round's scope; call .eval()")
+            ctx = train.Dropout.apply(ctx, float(self.drop.p))
+        y1 = lin("o", self.out, ctx, q)
+        hdn = train.LayerNormC.apply(y1, self.ffn[0].weight, self.ffn[0].bias, None, self.ffn[0].eps, fb)
+        hdn = train.Gelu.apply(lin("f1", self.ffn[1], hdn))
+        return lin("f3", self.ffn[3], hdn, y1)
+
+    def forward(self, zt_prev, za):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            B, C, Tq = zt_prev.shape
+            fold = lambda x: x.permute(1, 0, 2).reshape(1, C, -1).contiguous()
+            y = self.run_train(fold(zt_prev), fold(za), B)
+            return y.reshape(C, B, Tq).permute(1, 0, 2).contiguous()
+        if self.training and self.drop.p > 0:
+            raise MvqError("CrossPredictor: train-mode dropout needs autograd enabled; call .eval() for inference")
         return self.run(zt_prev, za)
 
 
@@ -197,6 +219,39 @@ class _ProposedBase(nn.Module):
         return z_run, r_tokens
 
 
+    def _ar_latents_train(self, qa, zt):
+        """The same loop recorded for autograd: z_hat of chunk c feeds column 0 of chunk c+1's zt_prev WITH gradient
+        (the reference writes z_hat into z_run in place and slices it back, Training/...5.py:303-319)."""
+        B, C, Tlat = zt.shape
+        dev = zt.device
+        ln = self.tokennorm.ln
+        chunks, r_toks, prev = [], [], None
+        for s in range(0, Tlat, AR_CHUNK_TOK):
+            e = min(Tlat, s + AR_CHUNK_TOK)
+            n = e - s
+            zt_c = ops.fold_time_slice(zt, s, e)
+            if prev is None:
+                zt_prev = torch.zeros(1, C, B * n, device=dev, dtype=torch.float32)
+            else:
+                last = prev.reshape(C, B, -1)[:, :, -1:]                                 # z_run[..., s-1], with graph
+                zt_prev = torch.cat([last, torch.zeros(C, B, n - 1, device=dev)], dim=2).reshape(1, C, B * n)
+            ka = min(qa.shape[-1], e) - min(qa.shape[-1], s)
+            qa_c = ops.fold_time_slice(qa, s, s + ka) if ka > 0 else torch.zeros(1, C, 0, device=dev)
+            z_pred = self.predict.run_train(zt_prev, qa_c, B)
+            r = ops.sub(zt_c, z_pred.detach())
+            u = train.LayerNormC.apply(r, ln.weight, ln.bias, None, ln.eps, B)
+            rN = train.ScaleTanh.apply(u, self.scale)
+            rD = train.Linear.apply(rN, self.proj_down.weight, self.proj_down.bias, None, self._pd)
+            qD = train.RvqSte.apply(rD, self.vq.stacked(), None)
+            z_hat = train.Linear.apply(qD, self.proj_up.weight, self.proj_up.bias, z_pred, self._pu)
+            chunks.append(z_hat.reshape(C, B, n))
+            r_toks.append(rD.detach().reshape(CODE_DIM, B, n))
+            prev = z_hat
+        z_run = torch.cat(chunks, dim=2).permute(1, 0, 2).contiguous()
+        r_tokens = torch.cat(r_toks, dim=2).permute(1, 0, 2).contiguous()
+        return z_run, r_tokens
+
+
 class ProposedEval(_ProposedBase):
     """Evaluation/dac_vcpwq_proposed6_latency.py:437-487."""
 
@@ -246,16 +301,22 @@ class ProposedEval(_ProposedBase):
 
 
 class AllPredAR(_ProposedBase):
-    """Training/compare_dacvsproposal_5.py:279-326 -- forward pass only (eval semantics)."""
+    """Training/compare_dacvsproposal_5.py:279-326.  Under ``torch.no_grad()`` (validation, ...:411-414) this is the
+    fused inference path; with autograd enabled it records the HIP-backed graph of train.py for ``.backward()``."""
 
-    @torch.no_grad()
     def forward_step(self, a_1T, tc_1T):
         Tw = tc_1T.shape[-1]
-        za = self.A_ENC(a_1T)
-        qa, *_ = self.A_QUANT(za)
-        zt = self.T_ENC(tc_1T)
-        z_run, r_tokens = self._ar_latents(qa, zt, None, want_tokens=True)
-        y_hat = self.T_DEC(z_run)
+        with torch.no_grad():                                                  # frozen backbones: no graph
+            za = self.A_ENC(a_1T)
+            qa, *_ = self.A_QUANT(za)
+            zt = self.T_ENC(tc_1T)
+        if torch.is_grad_enabled() and zt.numel() and any(p.requires_grad for p in self.parameters()):
+            z_run, r_tokens = self._ar_latents_train(qa, zt)
+            y_hat = self.T_DEC(z_run)                                          # _DecoderInputGrad: HIP backward w.r.t. z
+        else:
+            with torch.no_grad():
+                z_run, r_tokens = self._ar_latents(qa, zt, None, want_tokens=True)
+                y_hat = self.T_DEC(z_run)
         T = min(y_hat.shape[-1], tc_1T.shape[-1], Tw)
         fz = lambda x: torch.nan_to_num(x, nan=0.0, posinf=0.0, neginf=0.0)   # finite_or_zero (...5.py:99-100)
         return {"y_hat": fz(y_hat[..., :T]), "tgt": fz(tc_1T[..., :T]), "r_tokens": r_tokens}

@@ -305,3 +305,32 @@ class ProposedEval(nn.Module):
     @torch.no_grad()
     def forward_eval(self, a, t, books_use=None, tactile_only=False):
         return self.T_DEC(self.encode_latents(a, t, books_use, tactile_only))
+
+    def forward_step(self, a, tc):
+        """The reference's training forward WITH autograd (Training/compare_dacvsproposal_5.py:293-326): z_run is
+        written in place chunk by chunk, so chunk c+1's zt_prev column 0 carries gradient into chunk c's z_hat;
+        z_pred is detached inside the residual; the RVQ is straight-through.  Gradient oracle for tests/test_gpu_train.py."""
+        Tw = tc.shape[-1]
+        with torch.no_grad():
+            qa, *_ = self.A_QUANT(self.A_ENC(a))
+            zt = self.T_ENC(tc)
+        B, C, Tlat = zt.shape
+        z_run = torch.zeros_like(zt)
+        rD_all = []
+        for s in range(0, Tlat, self.chunk):
+            e = min(Tlat, s + self.chunk)
+            zt_prev = torch.zeros(B, C, e - s)
+            if s == 0:
+                zt_prev[..., 1:] = z_run[..., s:e - 1]
+            else:
+                zt_prev[...] = z_run[..., s - 1:e - 1]
+            z_pred = self.predict(zt_prev, qa[..., s:e])
+            r = zt[..., s:e] - z_pred.detach()
+            rN = torch.tanh(self.tokennorm(r))
+            rD = self.proj_down(self.scale.clamp(5e-3, 0.5) * rN)
+            qD = self.vq(rD)
+            z_run[..., s:e] = z_pred + self.proj_up(qD)
+            rD_all.append(rD.detach())
+        y_hat = self.T_DEC(z_run)
+        T = min(y_hat.shape[-1], tc.shape[-1], Tw)
+        return {"y_hat": y_hat[..., :T], "tgt": tc[..., :T], "r_tokens": torch.cat(rD_all, dim=-1)}

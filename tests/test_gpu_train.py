@@ -1,0 +1,179 @@
+"""-m gpu: backward of the reference's trainable head -- the HIP-backed autograd Functions
+of train.py against torch autograd on the torch restatement (oracle/dac24_torch.py), op by op and through the whole
+AllPredAR training forward.  Forward values are the bit-exact inference kernels (asserted); gradients are compared at
+fp32 tolerance: relative L2 error <= 2e-4 per tensor (different but fixed summation orders on the two sides)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def rel(got, want):
+    got = got.detach().double().cpu().reshape(-1); want = want.detach().double().cpu().reshape(-1)
+    return float((got - want).norm() / want.norm().clamp_min(1e-30))
+
+
+def fold(x):
+    B, C, T = x.shape
+    return x.permute(1, 0, 2).reshape(1, C, B * T).contiguous()
+
+
+def unfold(x, B):
+    _, C, N = x.shape
+    return x.reshape(C, B, N // B).permute(1, 0, 2)
+
+
+def test_layernorm_gelu_scale_tanh_backward(dev):
+    from multimodal_vqvae_compression_audio_tactile_amd import train, synth
+    g = torch.Generator().manual_seed(0)
+    B, C, T = 3, 96, 5
+    x = torch.randn(B, C, T, generator=g, dtype=torch.float64)
+    gam = 1 + 0.1 * torch.randn(C, generator=g, dtype=torch.float64); bet = 0.1 * torch.randn(C, generator=g, dtype=torch.float64)
+    pe = synth.pos_table(C, 16)
+    go = torch.randn(B, C, T, generator=g, dtype=torch.float64)
+    scale = torch.tensor(0.08, dtype=torch.float64)
+    xr, gr, br, sr = (t.clone().requires_grad_(True) for t in (x, gam, bet, scale))
+    u = F.layer_norm((xr + pe[:T].T.double().unsqueeze(0)).permute(0, 2, 1), (C,), gr, br, 1e-5).permute(0, 2, 1)
+    y = sr.clamp(5e-3, 0.5) * torch.tanh(F.gelu(u))
+    (y * go).sum().backward()
+    xd, gd, bd, sd_ = (t.float().to(dev).requires_grad_(True) for t in (fold(x), gam, bet, scale))
+    ud = train.LayerNormC.apply(xd, gd, bd, pe.to(dev), 1e-5, B)
+    yd = train.ScaleTanh.apply(train.Gelu.apply(ud), sd_)
+    (yd * fold(go).float().to(dev)).sum().backward()
+    assert rel(unfold(yd, B), y) < 1e-5
+    assert rel(unfold(xd.grad, B), xr.grad) < TOL
+    assert rel(gd.grad, gr.grad) < TOL and rel(bd.grad, br.grad) < TOL
+    assert rel(sd_.grad, sr.grad) < TOL
+    # scale outside the clamp range: no gradient reaches it (torch.clamp semantics)
+    s2 = torch.tensor(0.9, device=dev, requires_grad=True)
+    train.ScaleTanh.apply(ud.detach(), s2).sum().backward()
+    assert float(s2.grad) == 0.0
+
+
+@pytest.mark.parametrize("Tq,Tk", [(16, 16), (11, 11), (16, 5)])
+def test_attention_backward(Tq, Tk, dev):
+    from multimodal_vqvae_compression_audio_tactile_amd import train
+    g = torch.Generator().manual_seed(Tq * 31 + Tk)
+    B, H, dh = 3, 4, 8
+    C = H * dh
+    q, k, v = (torch.randn(B, C, t, generator=g, dtype=torch.float64) for t in (Tq, Tk, Tk))
+    go = torch.randn(B, C, Tq, generator=g, dtype=torch.float64)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    sp = lambda x: x.permute(0, 2, 1).reshape(B, -1, H, dh).permute(0, 2, 1, 3)
+    att = (sp(qr) @ sp(kr).transpose(-2, -1)) / math.sqrt(dh)
+    ctx = (att.softmax(-1) @ sp(vr)).permute(0, 2, 1, 3).reshape(B, Tq, C).permute(0, 2, 1)
+    (ctx * go).sum().backward()
+    qd, kd, vd = (fold(t).float().to(dev).requires_grad_(True) for t in (q, k, v))
+    cd = train.Attention.apply(qd, kd, vd, H, B)
+    (cd * fold(go).float().to(dev)).sum().backward()
+    assert rel(unfold(cd, B), ctx) < 1e-5
+    for got, want in ((qd.grad, qr.grad), (kd.grad, kr.grad), (vd.grad, vr.grad)):
+        assert rel(unfold(got, B), want) < TOL
+
+
+@pytest.mark.parametrize("O,I,N,bias,res", [(96, 1024, 48, True, False), (1024, 96, 33, True, True), (256, 128, 64, False, True)])
+def test_linear_backward(O, I, N, bias, res, dev):
+    from multimodal_vqvae_compression_audio_tactile_amd import train
+    from multimodal_vqvae_compression_audio_tactile_amd.proposed import _PackedLinear
+    g = torch.Generator().manual_seed(O + I + N)
+    mod = torch.nn.Conv1d(I, O, 1, bias=bias)
+    with torch.no_grad():
+        mod.weight.copy_(torch.randn(O, I, 1, generator=g) / math.sqrt(I))
+        if bias:
+            mod.bias.copy_(torch.randn(O, generator=g))
+    x = torch.randn(1, I, N, generator=g); r = torch.randn(1, O, N, generator=g) if res else None
+    go = torch.randn(1, O, N, generator=g)
+    ref = torch.nn.Conv1d(I, O, 1, bias=bias).double(); ref.load_state_dict({k_: v_.double() for k_, v_ in mod.state_dict().items()})
+    xr = x.double().requires_grad_(True); rr = r.double().requires_grad_(True) if res else None
+    yr = ref(xr) + (rr if res else 0)
+    (yr * go.double()).sum().backward()
+    mod = mod.to(dev)
+    xd = x.to(dev).requires_grad_(True); rd = r.to(dev).requires_grad_(True) if res else None
+    yd = train.Linear.apply(xd, mod.weight, mod.bias, rd, _PackedLinear(mod))
+    (yd * go.to(dev)).sum().backward()
+    assert rel(yd, yr) < 1e-5
+    assert rel(xd.grad, xr.grad) < TOL and rel(mod.weight.grad, ref.weight.grad) < TOL
+    if bias:
+        assert rel(mod.bias.grad, ref.bias.grad) < TOL
+    if res:
+        assert torch.equal(rd.grad.cpu(), go)
+
+
+def _loss(out, wy):
+    y, tgt = out["y_hat"], out["tgt"]
+    return (y - tgt).abs().mean() + (y * wy[..., :y.shape[-1]]).mean()
+
+
+def test_allpredar_training_gradients(dev):
+    """Whole training forward + backward (Training/compare_dacvsproposal_5.py:379-393): gradients of every trainable
+    parameter against torch autograd on the restatement; 24 tokens = two AR chunks, so the z_hat -> next zt_prev path and
+    the decoder input-gradient are both exercised.  vq.books and the frozen backbones must receive no gradient."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle import dac24_torch as O
+    from multimodal_vqvae_compression_audio_tactile_amd import AllPredAR, build_proposed, synth
+    sd = synth.proposed_model_state(23, rvq_books=3, rvq_embed=128)
+    T = 320 * 24
+    a = synth.audio_segments(2, seed=9, T=T); t = synth.tactile_segments(2, seed=9, T=T)
+    wy = 0.05 * torch.randn(2, 1, T, generator=torch.Generator().manual_seed(4))
+
+    ref = O.ProposedEval(rvq_books=3, rvq_embed=128)
+    ref.load_state_dict({k: v for k, v in sd.items() if k != "predict.pos.pe"}, strict=False)
+    ref.eval()
+    for m in (ref.A_ENC, ref.A_QUANT, ref.T_ENC, ref.T_DEC):
+        for p in m.parameters():
+            p.requires_grad_(False)
+    out_r = ref.forward_step(a, t)
+    _loss(out_r, wy).backward()
+
+    net = build_proposed(sd, rvq_books=3, rvq_embed=128, device=dev, cls=AllPredAR)       # .eval(): dropout off
+    out = net.forward_step(a.to(dev), t.to(dev))
+    with torch.no_grad():
+        out_inf = net.forward_step(a.to(dev), t.to(dev))
+    assert torch.equal(out["y_hat"], out_inf["y_hat"]) and torch.equal(out["r_tokens"], out_inf["r_tokens"])
+    assert rel(out["y_hat"], out_r["y_hat"]) < 1e-3
+    _loss(out, wy.to(dev)).backward()
+
+    named_r = dict(ref.named_parameters())
+    checked, worst = 0, 0.0
+    for name, p in net.named_parameters():
+        if name.startswith("vq.books") or name.split(".")[0] in ("A_ENC", "A_QUANT", "T_ENC", "T_DEC"):
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None, name
+        want = named_r[name].grad
+        assert float(want.norm()) > 0, name
+        err = rel(p.grad, want)
+        print(f"  {name:28s} |g| {float(want.norm()):.3e}  rel err {err:.2e}")
+        worst = max(worst, err)
+        assert err < TOL, (name, err)
+        checked += 1
+    assert checked == 21          # 6 LN pairs... : ln_q, ln_kv, ffn.0, tokennorm (w+b), q/k/v/out, ffn.1/.3 (w+b), scale, proj_down/up (w+b)
+    print(f"worst relative gradient error over {checked} tensors: {worst:.2e}")
+    # one optimiser step moves the parameters and the next forward sees them (packed-weight caches invalidate)
+    opt = torch.optim.AdamW([p for n, p in net.named_parameters() if p.requires_grad and not n.startswith("vq.books")], lr=2e-4)
+    before = net.proj_up.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, net.proj_up.weight.detach())
+    with torch.no_grad():
+        out2 = net.forward_step(a.to(dev), t.to(dev))
+    assert not torch.equal(out2["y_hat"], out_inf["y_hat"])
+
+
+def test_dropout_train_mode(dev):
+    """net.train(): the ctx dropout (p = 0.1, Training/...5.py:242) is applied with inverted scaling and its mask reused in
+    backward; eval() is the identity."""
+    from multimodal_vqvae_compression_audio_tactile_amd import train
+    x = torch.randn(1, 64, 512, device=dev, requires_grad=True)
+    torch.manual_seed(0)
+    y = train.Dropout.apply(x, 0.1)
+    keep = (y != 0)
+    assert 0.85 < keep.float().mean().item() < 0.95
+    assert torch.allclose(y[keep], x.detach()[keep] / 0.9)
+    y.sum().backward()
+    assert torch.allclose(x.grad[keep], torch.full_like(x.grad[keep], 1 / 0.9)) and float(x.grad[~keep].abs().sum()) == 0.0
