@@ -12,6 +12,11 @@ patched) and records inputs-by-seed + expected outputs of:
   G4 ProposedEval.encode_latents / forward_eval (Evaluation/dac_vcpwq_proposed6_latency.py:451-487) driven with the
      torch restatement of the DAC backbones as A_ENC / A_QUANT / T_ENC / T_DEC (the real `dac` package is absent)
   G6 align_by_xcorr                   (Evaluation/dac_vcpwq_proposed6_latency.py:164-202)
+  G7 one training step's loss and gradients: the reference's AllPredAR.forward_step (Training/...5.py:293-326) on the
+     restated backbones, its MultiResSTFTLoss / MelCosineLoss / safe_l1 (...:150-211; torchaudio's MelScale replaced by
+     oracle/losses_torch.MelScale because torchaudio is absent), total = .55/.25/.20 mix, autograd backward (eval mode:
+     dropout off; fp32, no autocast).  Stored: the losses, y_hat, dL/dy_hat and for every trainable tensor its norm
+     and the subsample flat[::997].
   G5 psnr_batch / psnr_global_peak_db (Evaluation/compare_dacvsproposal_5_eval.py:180-185, ...6_latency.py:204-214)
 Only data is stored (arrays), never reference source.  Inputs are re-created from seeds by tests/golden_inputs.py.
 """
@@ -111,11 +116,36 @@ def main():
     np.savez_compressed(OUT / "g5_psnr.npz", **g5)
     # ---- G6: align_by_xcorr (Evaluation/dac_vcpwq_proposed6_latency.py:164-202)
     g6 = {}
-    for name, (T, shift, noise, seed) in gi.ALIGN_CASES.items():
-        ref, est = gi.align_inputs(T, shift, noise, seed)
+    for name, (Tlen, shift, noise, seed) in gi.ALIGN_CASES.items():
+        ref, est = gi.align_inputs(Tlen, shift, noise, seed)
         r_a, e_a, s = ev.align_by_xcorr(torch.from_numpy(ref), torch.from_numpy(est), 200)
         g6[f"{name}.shift"] = np.array(s); g6[f"{name}.ref_a"] = r_a.numpy(); g6[f"{name}.est_a"] = e_a.numpy()
     np.savez_compressed(OUT / "g6_align.npz", **g6)
+    # ---- G7: training step (loss + gradients) from the reference's own classes
+    from oracle import losses_torch as LT
+    books, K, B, seed, Tn = gi.TRAIN_CASE
+    with torch.enable_grad():
+        sdm = gi.model_state(seed, books, K)
+        a, t = gi.train_inputs()
+        da, dt = T.DAC(), T.DAC()
+        net = tr.AllPredAR(da.encoder, da.quantizer, dt.encoder, dt.decoder, c_lat=1024, rvq_books=books, rvq_embed=K)
+        net.load_state_dict({k: v for k, v in sdm.items()}, strict=True)
+        net.eval()
+        mr, mc = tr.MultiResSTFTLoss(), tr.MelCosineLoss()
+        mc.mel = LT.MelScale(n_mels=64, sample_rate=24000, n_stft=257, f_min=0.0, f_max=12000.0)
+        out = net.forward_step(a, t)
+        y = out["y_hat"]; y.retain_grad()
+        l1, st, me = tr.safe_l1(y, out["tgt"]), mr(y, out["tgt"]), mc(y, out["tgt"])
+        total = tr.W_WAV_L1 * l1 + tr.W_STFT * st + tr.W_MELCOS * me
+        total.backward()
+    g7 = {"losses": np.array([float(l1), float(st), float(me), float(total)], np.float64),
+          "y_hat": y.detach().numpy(), "dy": y.grad.numpy(), "r_tokens": out["r_tokens"].numpy()}
+    for name, p_ in net.named_parameters():
+        if p_.requires_grad and not name.startswith("vq.books"):
+            g7[f"norm.{name}"] = np.array(float(p_.grad.norm()), np.float64)
+            g7[f"sub.{name}"] = p_.grad.reshape(-1)[::gi.GRAD_STRIDE].numpy().copy()
+    assert all(p_.grad is None for n_, p_ in net.named_parameters() if n_.split(".")[0] in ("A_ENC", "A_QUANT", "T_ENC", "T_DEC"))
+    np.savez_compressed(OUT / "g7_train_step.npz", **g7)
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size // 1024, "KiB")
 

@@ -19,6 +19,9 @@ CP_CASES = {"t16_16": (2, 16, 16, 301), "t11_11": (2, 11, 11, 302), "t16_9": (1,
 # name: (rvq_books, K, books_use, B, seed)
 PE_CASES = {"b8_k512": (8, 512, None, 2, 7), "b3_k128_use2": (3, 128, 2, 1, 9)}
 T_SHORT = 320 * 35
+# G7 training step: (rvq_books, K, B, seed, T)  -- 24 tokens = two AR chunks (gradient crosses the chunk boundary)
+TRAIN_CASE = (3, 128, 2, 23, 320 * 24)
+GRAD_STRIDE = 997            # stored subsample of every gradient tensor: flat[::GRAD_STRIDE]
 
 
 def rvq_inputs(K, nb, B, T, seed):
@@ -49,6 +52,12 @@ def model_state(seed, books, K):
 def pe_inputs(B, seed):
     from multimodal_vqvae_compression_audio_tactile_amd import synth
     return synth.audio_segments(B, seed=seed, T=T_SHORT), synth.tactile_segments(B, seed=seed, T=T_SHORT)
+
+
+def train_inputs():
+    from multimodal_vqvae_compression_audio_tactile_amd import synth
+    books, K, B, seed, T = TRAIN_CASE
+    return synth.audio_segments(B, seed=seed, T=T), synth.tactile_segments(B, seed=seed, T=T)
 
 
 # name: (T, true_shift, noise, seed)   -- signals at the tactile rate (3 kHz), max_shift 200 as in the reference
