@@ -230,6 +230,39 @@ int mvq_mul_scaled_f32(const float* a, const float* b, float scale, float* out, 
 int mvq_transpose2d_f32(const float* in, float* out, int rows, int cols, void* stream);
 int mvq_rowsum_f32(const float* in, float* out, int rows, int cols, int accumulate, void* stream);
 
+/* Training losses: safe_l1, MultiResSTFTLoss, MelCosineLoss of
+ * Training/compare_dacvsproposal_5.py:150-211 and their gradient w.r.t. the predicted waveform.  The STFT is a GEMM:
+ * frames[n_fft, cols] (windowed, reflect-padded, center=True) times a real DFT basis -> spec[2*fp, cols] on
+ * mvq_conv1d_f32 (k = 1), rows [0,f) = Re, rows [fp, fp+f) = Im, f = n_fft/2+1, fp = f rounded up to 8; its gradient is
+ * the transposed GEMM followed by overlap_add.  Column = half*batch*nframes + b*nframes + n, half 0 = prediction,
+ * half 1 = target, ncols >= 2*batch*nframes, nframes = 1 + t/hop.  These entry points are the HBM-bound glue:
+ *   stft_frames       out[f][col0 + b*nframes + n] = window[f] * finite_or_zero(x[b][reflect(n*hop + f - n_fft/2)])
+ *   spec_mag          mag[k][c] = max(|spec|, eps)   (rows f..fp-1 zero)
+ *   spec_loss_partial partial[3][batch][p]: sums of (X-Y)^2, Y^2, |X-Y| per item (spectral convergence and log-free
+ *                     magnitude L1 of MultiResSTFTLoss.forward, ...:166-170)
+ *   spec_grad         g[2*fp][batch*nframes] = dL/d(Re,Im) of the prediction from coef_a[b]*(X-Y) + coef_b*sign(X-Y)
+ *                     + extra[k][c] (extra: gradient arriving from the mel branch, may be NULL)
+ *   overlap_add       dy[b][t] += sum of window*dframes over the frames (and reflections) covering sample t
+ *   l1_loss           partial[p] block sums of |y - tgt| (finite_or_zero applied); dy += coef*sign(y - tgt) if dy
+ *   mel_max / mel_cos / mel_max_grad : per-item max of the mel spectrogram (MelCosineLoss._mel_mag's amax), the per-frame
+ *                     cosine of log(M/max + eps) and its gradient w.r.t. the prediction's mel magnitudes (dmel[n_mels]
+ *                     [batch*nframes], dden per column; mel_max_grad routes the max's gradient to its argmax element)
+ * Checked against torch autograd on the restated losses and fixture G7 (fp32 tolerance). */
+int mvq_stft_frames_f32(const float* x, const float* window, float* out, int batch, int t, int n_fft, int hop, int nframes,
+                        size_t ncols, size_t col0, void* stream);
+int mvq_spec_mag_f32(const float* spec, float* mag, int f, int fp, size_t ncols, float eps, void* stream);
+int mvq_spec_loss_partial_f32(const float* mag, float* partial, int p, int f, int batch, int nframes, size_t ncols, void* stream);
+int mvq_spec_grad_f32(const float* spec, const float* mag, const float* coef_a, float coef_b, const float* extra, float* g,
+                      int f, int fp, int batch, int nframes, size_t ncols, float eps, void* stream);
+int mvq_overlap_add_f32(const float* dframes, const float* window, float* dy, int batch, int t, int n_fft, int hop, int nframes,
+                        void* stream);
+int mvq_l1_loss_f32(const float* y, const float* tgt, float* partial, int p, float* dy, float coef, size_t n, void* stream);
+int mvq_mel_max_f32(const float* mel, float* maxv, int* argmax, int n_mels, int batch, int nframes, size_t ncols, void* stream);
+int mvq_mel_cos_f32(const float* mel, const float* maxv, float* cosv, float* dmel, float* dden, float coef, int n_mels, int batch,
+                    int nframes, size_t ncols, float eps, void* stream);
+int mvq_mel_max_grad_f32(const float* dden, const float* maxv, const int* argmax, float* dmel, int batch, int nframes, float eps,
+                         void* stream);
+
 /* out = g * (1 - y*y): backward of the decoder's final tanh (y = saved output). */
 int mvq_mul_dtanh_f32(const float* g, const float* y, float* out, size_t n, void* stream);
 

@@ -53,6 +53,15 @@ EXPORTS = {
     "mvq_mul_scaled_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "mvq_transpose2d_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mvq_rowsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mvq_stft_frames_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_size_t] * 2 + [c_void_p]),
+    "mvq_spec_mag_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, c_float, c_void_p]),
+    "mvq_spec_loss_partial_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_size_t, c_void_p]),
+    "mvq_spec_grad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p] + [c_int] * 4 + [c_size_t, c_float, c_void_p]),
+    "mvq_overlap_add_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
+    "mvq_l1_loss_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_size_t, c_void_p]),
+    "mvq_mel_max_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_size_t, c_void_p]),
+    "mvq_mel_cos_f32": (c_int, [c_void_p] * 5 + [c_float] + [c_int] * 3 + [c_size_t, c_float, c_void_p]),
+    "mvq_mel_max_grad_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p]),
     "mvq_gelu_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvq_sub3d_f32": (c_int, [c_void_p, c_size_t, c_size_t] * 3 + [c_int] * 3 + [c_void_p]),
     "mvq_copy3d_f32": (c_int, [c_void_p, c_size_t, c_size_t] * 2 + [c_int] * 3 + [c_void_p]),

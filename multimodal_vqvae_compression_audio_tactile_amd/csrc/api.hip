@@ -493,6 +493,60 @@ int mvq_rowsum_f32(const float* in, float* out, int rows, int cols, int accumula
     return e == hipSuccess ? MVQ_OK : hipfail(e, "rowsum");
 }
 
+/* training losses (row f2): the glue kernels around the STFT-as-GEMM; see include/mvq.h */
+#define MVQ_LOSS_CALL(cond, what, call) do { if (cond) return fail(MVQ_EINVAL, what ": bad argument"); \
+    hipError_t e_ = (call); return e_ == hipSuccess ? MVQ_OK : hipfail(e_, what); } while (0)
+
+int mvq_stft_frames_f32(const float* x, const float* window, float* out, int batch, int t, int n_fft, int hop, int nframes,
+                        size_t ncols, size_t col0, void* stream)
+{
+    MVQ_LOSS_CALL(!x || !window || !out || batch < 0 || t <= n_fft / 2 || n_fft <= 0 || hop <= 0 || nframes != 1 + t / hop ||
+                  col0 + (size_t)batch * nframes > ncols, "stft_frames",
+                  mvq::launch_stft_frames(x, window, out, batch, t, n_fft, hop, nframes, ncols, col0, S(stream)));
+}
+int mvq_spec_mag_f32(const float* spec, float* mag, int f, int fp, size_t ncols, float eps, void* stream)
+{
+    MVQ_LOSS_CALL(!spec || !mag || f <= 0 || fp < f, "spec_mag", mvq::launch_spec_mag(spec, mag, f, fp, ncols, eps, S(stream)));
+}
+int mvq_spec_loss_partial_f32(const float* mag, float* partial, int p, int f, int batch, int nframes, size_t ncols, void* stream)
+{
+    MVQ_LOSS_CALL(!mag || !partial || p <= 0 || f <= 0 || batch < 0 || (size_t)2 * batch * nframes > ncols, "spec_loss_partial",
+                  mvq::launch_spec_loss_partial(mag, partial, p, f, batch, nframes, ncols, S(stream)));
+}
+int mvq_spec_grad_f32(const float* spec, const float* mag, const float* coef_a, float coef_b, const float* extra, float* g,
+                      int f, int fp, int batch, int nframes, size_t ncols, float eps, void* stream)
+{
+    MVQ_LOSS_CALL(!spec || !mag || !g || f <= 0 || fp < f || batch < 0 || (size_t)2 * batch * nframes > ncols, "spec_grad",
+                  mvq::launch_spec_grad(spec, mag, coef_a, coef_b, extra, g, f, fp, batch, nframes, ncols, eps, S(stream)));
+}
+int mvq_overlap_add_f32(const float* dframes, const float* window, float* dy, int batch, int t, int n_fft, int hop, int nframes,
+                        void* stream)
+{
+    MVQ_LOSS_CALL(!dframes || !window || !dy || batch < 0 || t <= n_fft / 2 || hop <= 0 || nframes != 1 + t / hop, "overlap_add",
+                  mvq::launch_overlap_add(dframes, window, dy, batch, t, n_fft, hop, nframes, S(stream)));
+}
+int mvq_l1_loss_f32(const float* y, const float* tgt, float* partial, int p, float* dy, float coef, size_t n, void* stream)
+{
+    MVQ_LOSS_CALL(!y || !tgt || !partial || p <= 0 || p > 4096, "l1_loss", mvq::launch_l1_loss(y, tgt, partial, p, dy, coef, n, S(stream)));
+}
+int mvq_mel_max_f32(const float* mel, float* maxv, int* argmax, int n_mels, int batch, int nframes, size_t ncols, void* stream)
+{
+    MVQ_LOSS_CALL(!mel || !maxv || !argmax || n_mels <= 0 || batch < 0 || (size_t)2 * batch * nframes > ncols, "mel_max",
+                  mvq::launch_mel_max(mel, maxv, argmax, n_mels, batch, nframes, ncols, S(stream)));
+}
+int mvq_mel_cos_f32(const float* mel, const float* maxv, float* cosv, float* dmel, float* dden, float coef, int n_mels, int batch,
+                    int nframes, size_t ncols, float eps, void* stream)
+{
+    MVQ_LOSS_CALL(!mel || !maxv || !cosv || (dmel && !dden) || n_mels <= 0 || batch < 0 || (size_t)2 * batch * nframes > ncols, "mel_cos",
+                  mvq::launch_mel_cos(mel, maxv, cosv, dmel, dden, coef, n_mels, batch, nframes, ncols, eps, S(stream)));
+}
+int mvq_mel_max_grad_f32(const float* dden, const float* maxv, const int* argmax, float* dmel, int batch, int nframes, float eps,
+                         void* stream)
+{
+    MVQ_LOSS_CALL(!dden || !maxv || !argmax || !dmel || batch < 0, "mel_max_grad",
+                  mvq::launch_mel_max_grad(dden, maxv, argmax, dmel, batch, nframes, eps, S(stream)));
+}
+
 int mvq_mul_dtanh_f32(const float* g, const float* y, float* out, size_t n, void* stream)
 {
     if ((!g || !y || !out) && n) return fail(MVQ_EINVAL, "mul_dtanh: null tensor");

@@ -44,6 +44,18 @@ hipError_t launch_attention_bwd(const float* q, const float* k, const float* v, 
 hipError_t launch_mul_scaled(const float* a, const float* b, float scale, float* out, size_t n, hipStream_t s);
 hipError_t launch_transpose2d(const float* in, float* out, int rows, int cols, hipStream_t s);
 hipError_t launch_rowsum(const float* in, float* out, int rows, int cols, int accumulate, hipStream_t s);
+hipError_t launch_stft_frames(const float* x, const float* window, float* out, int B, int T, int n_fft, int hop, int nframes,
+                              size_t ncols, size_t col0, hipStream_t s);
+hipError_t launch_spec_mag(const float* S, float* mag, int F, int Fp, size_t ncols, float eps, hipStream_t s);
+hipError_t launch_spec_loss_partial(const float* mag, float* partial, int P, int F, int B, int nframes, size_t ncols, hipStream_t s);
+hipError_t launch_spec_grad(const float* S, const float* mag, const float* coefA, float coefB, const float* extra, float* G,
+                            int F, int Fp, int B, int nframes, size_t ncols, float eps, hipStream_t s);
+hipError_t launch_overlap_add(const float* dF, const float* window, float* dy, int B, int T, int n_fft, int hop, int nframes, hipStream_t s);
+hipError_t launch_l1_loss(const float* y, const float* tgt, float* partial, int P, float* dy, float coef, size_t n, hipStream_t s);
+hipError_t launch_mel_max(const float* M, float* maxv, int* argm, int n_mels, int B, int nframes, size_t ncols, hipStream_t s);
+hipError_t launch_mel_cos(const float* M, const float* maxv, float* cosv, float* dM, float* dden, float coef, int n_mels, int B,
+                          int nframes, size_t ncols, float eps, hipStream_t s);
+hipError_t launch_mel_max_grad(const float* dden, const float* maxv, const int* argm, float* dM, int B, int nframes, float eps, hipStream_t s);
 hipError_t launch_align_xcorr(const float* r, const float* e, int T, int max_shift, float* corr, int* scratch_valid,
                               int* best_shift, hipStream_t s);
 

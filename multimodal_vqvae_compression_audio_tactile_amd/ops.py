@@ -428,3 +428,76 @@ def linear_wgrad(g, x):
     wp = pack_conv1d(g.reshape(O, N, 1))
     xt = transpose2d(x).reshape(1, N, I)
     return conv1d(xt, wp, O, 1).reshape(O, I)
+
+
+# ---------------------------------------------------------------------------------------- training losses (row f2)
+def stft_frames(x, window, out, col0, n_fft, hop):
+    """x[B,T] -> out[n_fft, ncols][:, col0 : col0 + B*nframes] (windowed, reflect-padded, center=True)."""
+    B, T = x.shape
+    nfr = 1 + T // hop
+    check(_lib.lib().mvq_stft_frames_f32(x.data_ptr(), window.data_ptr(), out.data_ptr(), B, T, n_fft, hop, nfr,
+                                         out.shape[1], col0, _stream()), "mvq_stft_frames_f32")
+
+
+def spec_mag(S, F, Fp, eps):
+    ncols = S.shape[-1]
+    mag = torch.empty(Fp, ncols, device=S.device, dtype=torch.float32)
+    check(_lib.lib().mvq_spec_mag_f32(S.data_ptr(), mag.data_ptr(), F, Fp, ncols, float(eps), _stream()), "mvq_spec_mag_f32")
+    return mag
+
+
+def spec_loss_sums(mag, F, B, nfr):
+    """-> [3, B]: per item sums of (X-Y)^2, Y^2, |X-Y|."""
+    P = 16
+    partial = torch.empty(3 * B, P, device=mag.device, dtype=torch.float32)
+    check(_lib.lib().mvq_spec_loss_partial_f32(mag.data_ptr(), partial.data_ptr(), P, F, B, nfr, mag.shape[1], _stream()),
+          "mvq_spec_loss_partial_f32")
+    return rowsum(partial).reshape(3, B)
+
+
+def spec_grad(S, mag, coef_a, coef_b, extra, F, Fp, B, nfr, eps):
+    G = torch.empty(2 * Fp, B * nfr, device=S.device, dtype=torch.float32)
+    check(_lib.lib().mvq_spec_grad_f32(S.data_ptr(), mag.data_ptr(), _p(coef_a), float(coef_b), _p(extra), G.data_ptr(),
+                                       F, Fp, B, nfr, mag.shape[1], float(eps), _stream()), "mvq_spec_grad_f32")
+    return G
+
+
+def overlap_add_(dy, dframes, window, n_fft, hop):
+    B, T = dy.shape
+    check(_lib.lib().mvq_overlap_add_f32(dframes.data_ptr(), window.data_ptr(), dy.data_ptr(), B, T, n_fft, hop,
+                                         1 + T // hop, _stream()), "mvq_overlap_add_f32")
+    return dy
+
+
+def l1_loss_sum(y, tgt, dy=None, coef=0.0):
+    """sum |finite_or_zero(y) - finite_or_zero(tgt)| (0-d device tensor); dy += coef*sign(...) when dy is given."""
+    n = y.numel()
+    P = max(1, min(1024, (n + 255) // 256))
+    partial = torch.empty(1, P, device=y.device, dtype=torch.float32)
+    check(_lib.lib().mvq_l1_loss_f32(y.data_ptr(), tgt.data_ptr(), partial.data_ptr(), P, _p(dy), float(coef), n, _stream()),
+          "mvq_l1_loss_f32")
+    return rowsum(partial).reshape(())
+
+
+def mel_max(M, n_mels, B, nfr):
+    maxv = torch.empty(2 * B, device=M.device, dtype=torch.float32)
+    argm = torch.empty(2 * B, device=M.device, dtype=torch.int32)
+    check(_lib.lib().mvq_mel_max_f32(M.data_ptr(), maxv.data_ptr(), argm.data_ptr(), n_mels, B, nfr, M.shape[-1], _stream()),
+          "mvq_mel_max_f32")
+    return maxv, argm
+
+
+def mel_cos(M, maxv, n_mels, B, nfr, eps, coef=None):
+    """-> cos[B*nfr] (, dM[n_mels, B*nfr], dden[B*nfr] when coef = dL/dcos is given)."""
+    cosv = torch.empty(B * nfr, device=M.device, dtype=torch.float32)
+    dM = torch.empty(n_mels, B * nfr, device=M.device, dtype=torch.float32) if coef is not None else None
+    dden = torch.empty(B * nfr, device=M.device, dtype=torch.float32) if coef is not None else None
+    check(_lib.lib().mvq_mel_cos_f32(M.data_ptr(), maxv.data_ptr(), cosv.data_ptr(), _p(dM), _p(dden),
+                                     float(coef or 0.0), n_mels, B, nfr, M.shape[-1], float(eps), _stream()), "mvq_mel_cos_f32")
+    return cosv, dM, dden
+
+
+def mel_max_grad_(dM, dden, maxv, argm, B, nfr, eps):
+    check(_lib.lib().mvq_mel_max_grad_f32(dden.data_ptr(), maxv.data_ptr(), argm.data_ptr(), dM.data_ptr(), B, nfr, float(eps),
+                                          _stream()), "mvq_mel_max_grad_f32")
+    return dM

@@ -28,6 +28,7 @@ def unfold(x, B):
     return x.reshape(C, B, N // B).permute(1, 0, 2)
 
 
+@torch.enable_grad()
 def test_layernorm_gelu_scale_tanh_backward(dev):
     from multimodal_vqvae_compression_audio_tactile_amd import train, synth
     g = torch.Generator().manual_seed(0)
@@ -56,6 +57,7 @@ def test_layernorm_gelu_scale_tanh_backward(dev):
 
 
 @pytest.mark.parametrize("Tq,Tk", [(16, 16), (11, 11), (16, 5)])
+@torch.enable_grad()
 def test_attention_backward(Tq, Tk, dev):
     from multimodal_vqvae_compression_audio_tactile_amd import train
     g = torch.Generator().manual_seed(Tq * 31 + Tk)
@@ -77,6 +79,7 @@ def test_attention_backward(Tq, Tk, dev):
 
 
 @pytest.mark.parametrize("O,I,N,bias,res", [(96, 1024, 48, True, False), (1024, 96, 33, True, True), (256, 128, 64, False, True)])
+@torch.enable_grad()
 def test_linear_backward(O, I, N, bias, res, dev):
     from multimodal_vqvae_compression_audio_tactile_amd import train
     from multimodal_vqvae_compression_audio_tactile_amd.proposed import _PackedLinear
@@ -109,6 +112,7 @@ def _loss(out, wy):
     return (y - tgt).abs().mean() + (y * wy[..., :y.shape[-1]]).mean()
 
 
+@torch.enable_grad()
 def test_allpredar_training_gradients(dev):
     """Whole training forward + backward (Training/compare_dacvsproposal_5.py:379-393): gradients of every trainable
     parameter against torch autograd on the restatement; 24 tokens = two AR chunks, so the z_hat -> next zt_prev path and
@@ -165,6 +169,52 @@ def test_allpredar_training_gradients(dev):
     assert not torch.equal(out2["y_hat"], out_inf["y_hat"])
 
 
+@torch.enable_grad()
+def test_training_step_matches_reference_fixture(dev):
+    """The reference's whole training step on the HIP path: AllPredAR.forward_step -> TrainingLoss (L1 + MRSTFT + MelCos)
+    -> backward, against fixture G7 = the reference's own classes (tests/golden/make_golden.py).  Then clip + AdamW as
+    the reference does (Training/compare_dacvsproposal_5.py:392-395) and the codebook EMA (...:396-397)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import golden_inputs as gi
+    from multimodal_vqvae_compression_audio_tactile_amd import AllPredAR, TrainingLoss, build_proposed
+    G7 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_train_step.npz"))
+    books, K, B, seed, T = gi.TRAIN_CASE
+    net = build_proposed(gi.model_state(seed, books, K), rvq_books=books, rvq_embed=K, device=dev, cls=AllPredAR)
+    a, t = gi.train_inputs()
+    crit = TrainingLoss()
+    out = net.forward_step(a.to(dev), t.to(dev))
+    total = crit(out["y_hat"], out["tgt"])
+    total.backward()
+    assert rel(out["r_tokens"], torch.from_numpy(G7["r_tokens"])) < 1e-5
+    assert rel(out["y_hat"], torch.from_numpy(G7["y_hat"])) < 1e-5
+    got = [float(crit.parts[k]) for k in ("l1", "stft", "mel")] + [float(total)]
+    assert np.allclose(got, G7["losses"], rtol=2e-3), (got, G7["losses"])
+    n, worst = 0, 0.0
+    for name, p in net.named_parameters():
+        if f"norm.{name}" not in G7.files:
+            assert p.grad is None, name
+            continue
+        want_n = float(G7[f"norm.{name}"])
+        assert abs(float(p.grad.norm()) - want_n) <= 2e-3 * want_n, name
+        sub, want = p.grad.reshape(-1)[::gi.GRAD_STRIDE].cpu(), torch.from_numpy(G7[f"sub.{name}"])
+        worst = max(worst, rel(sub, want))
+        n += 1
+    print(f"worst relative error of the sampled gradients over {n} tensors: {worst:.2e}")
+    assert n == 21 and worst < 5e-3
+    params = [p for nme, p in net.named_parameters() if p.requires_grad and not nme.startswith("vq.books")]
+    opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=1e-5)
+    gn = torch.nn.utils.clip_grad_norm_(params, 3.0)
+    assert torch.isfinite(gn)
+    opt.step()
+    net.vq.ema_step(out["r_tokens"])
+    with torch.no_grad():
+        o2 = net.forward_step(a.to(dev), t.to(dev))
+        l2 = crit(o2["y_hat"], o2["tgt"])
+    assert torch.isfinite(l2)
+
+
+@torch.enable_grad()
 def test_dropout_train_mode(dev):
     """net.train(): the ctx dropout (p = 0.1, Training/...5.py:242) is applied with inverted scaling and its mask reused in
     backward; eval() is the identity."""

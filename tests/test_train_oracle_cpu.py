@@ -15,6 +15,7 @@ from oracle import losses_torch as LT           # noqa: E402
 G7 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_train_step.npz"))
 
 
+@torch.enable_grad()
 def test_restated_training_step_matches_reference_fixture():
     books, K, B, seed, T = gi.TRAIN_CASE
     sd = gi.model_state(seed, books, K)
