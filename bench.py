@@ -31,7 +31,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-GFLOP_PER_SEGMENT = {"joint": 158.5, "tactile": 120.3}
+GFLOP_PER_SEGMENT = {"joint": 158.5, "tactile": 120.3}     # SURVEY.md section 8(d); "train" is measured, see below
 TOKENS_PER_SEGMENT = 75
 
 
@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="1-s segments per GPU per step")
-    ap.add_argument("--workload", choices=["joint", "tactile"], default="joint")
+    ap.add_argument("--workload", choices=["joint", "tactile", "train"], default="joint",
+                    help="joint / tactile: the inference round trip (the headline metric).  train: one whole training step of "
+                         "BASELINE.json configs[4] (forward_step + L1/MRSTFT/MelCos + backward + clip + AdamW + codebook EMA)")
     ap.add_argument("--books", type=int, default=8)
     ap.add_argument("--embed", type=int, default=512)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo for a "
@@ -142,6 +144,43 @@ def cpu_baseline(workload, books, embed, sd):
                       f"CPU fp32 restatement (oracle/dac24_torch.py), {threads} threads, warm-up {warm:.1f}s"}
 
 
+def cpu_baseline_train(books, embed, sd):
+    """One reference training step (restated: oracle/dac24_torch.forward_step + oracle/losses_torch + torch autograd +
+    AdamW) on the host cores at the reference's batch of 6."""
+    from oracle import dac24_torch as T, losses_torch as LT
+    from multimodal_vqvae_compression_audio_tactile_amd import synth
+    threads = host_cores()
+    torch.set_num_threads(threads)
+    net = T.ProposedEval(rvq_books=books, rvq_embed=embed)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    for m in (net.A_ENC, net.A_QUANT, net.T_ENC, net.T_DEC):
+        for p in m.parameters():
+            p.requires_grad_(False)
+    params = [p for n, p in net.named_parameters() if p.requires_grad and not n.startswith("vq.books")]
+    opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=1e-5)
+    B = 6
+    a, t = synth.audio_segments(B, seed=7), synth.tactile_segments(B, seed=7)
+    reps, spent = 0, 0.0
+    with torch.enable_grad():
+        while spent < 15.0 and reps < 4:
+            t0 = time.perf_counter()
+            out = net.forward_step(a, t)
+            total, _ = LT.total_loss(out["y_hat"], out["tgt"])
+            opt.zero_grad(set_to_none=True); total.backward()
+            torch.nn.utils.clip_grad_norm_(params, 3.0); opt.step()
+            dt = time.perf_counter() - t0
+            if reps or dt < 8.0:
+                spent += dt; reps += 1
+            else:
+                reps, spent = 1, dt
+    seg_s = B * reps / spent
+    return {"value": seg_s * TOKENS_PER_SEGMENT, "unit": "token-frames/s", "cores": threads, "kind": "port",
+            "segments_per_s": seg_s,
+            "sample": f"{reps} x training step on B={B} synthetic 1-s segments, torch {torch.__version__} CPU fp32 "
+                      f"restatement + autograd + AdamW (codebook EMA not included), {threads} threads"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -167,13 +206,36 @@ def main():
     from multimodal_vqvae_compression_audio_tactile_amd import ops, synth
 
     sd = synth.proposed_model_state(7, rvq_books=args.books, rvq_embed=args.embed)
-    net = mvq.build_proposed(sd, rvq_books=args.books, rvq_embed=args.embed, device=dev)
+    train = args.workload == "train"
+    net = mvq.build_proposed(sd, rvq_books=args.books, rvq_embed=args.embed, device=dev, cls=mvq.AllPredAR if train else None)
     B = args.batch
     a = synth.audio_segments(B, seed=7 + rank).to(dev)
     t = synth.tactile_segments(B, seed=7 + rank).to(dev)
     tact = args.workload == "tactile"
 
+    if train:
+        from multimodal_vqvae_compression_audio_tactile_amd import dist as mdist
+        net.train()                                              # ctx dropout on, as in the reference's epoch loop
+        crit = mvq.TrainingLoss()
+        params = [p for n, p in net.named_parameters() if p.requires_grad and not n.startswith("vq.books")]
+        opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=1e-5)          # Training/...5.py:54-55,367
+
     def step():
+        if train:                                                # Training/compare_dacvsproposal_5.py:379-397
+            with torch.enable_grad():
+                out = net.forward_step(a, t)
+                total = crit(out["y_hat"], out["tgt"])
+                opt.zero_grad(set_to_none=True)
+                total.backward()
+            if dist:
+                mdist.allreduce_grads(params, B)
+            torch.nn.utils.clip_grad_norm_(params, 3.0)
+            opt.step()
+            if dist:
+                mdist.ema_step_all_ranks(net.vq, out["r_tokens"])
+            else:
+                net.vq.ema_step(out["r_tokens"])
+            return out["y_hat"].detach()
         if tact:
             return net.forward_eval_tactile_only(t, books_use=None)
         return net.forward_eval(a, t, books_use=None)
@@ -221,8 +283,16 @@ def main():
                        "sharding": f"segments sharded over {world} GPU(s), no data-path collective",
                        "weights": "seeded variance-preserving random init of the DAC-24k architecture"},
         }
-        gf = GFLOP_PER_SEGMENT[args.workload]
-        line["path_tflops"] = seg_s * gf * 1e-3 / world            # per GPU, algorithmic
+        if train:
+            line["metric"] = "training step token-frames/sec (forward_step + losses + backward + AdamW + codebook EMA)"
+            line["config"]["workload"] = ("AllPredAR training step (BASELINE.json configs[4], compare_dacvsproposal_5.py:379-397): "
+                                          "frozen DAC encoders/quantiser/decoder, trainable CrossPredictor/TokenNorm/scale/proj, "
+                                          f"RVQ {args.books}x{args.embed}x96 with EMA update, loss 0.55 L1 + 0.25 MRSTFT + 0.20 MelCos, fp32")
+            line["config"]["sharding"] = (f"data parallel over {world} GPU(s): one flat-bucket gradient all-reduce (34 MB) "
+                                          "+ one token all-gather for the codebook EMA per step")
+        else:
+            gf = GFLOP_PER_SEGMENT[args.workload]
+            line["path_tflops"] = seg_s * gf * 1e-3 / world            # per GPU, algorithmic
         if kev:
             summ = kev.summary()
             dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
@@ -248,7 +318,8 @@ def main():
                                               for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])}}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(args.workload, args.books, args.embed, sd)
+                line["cpu_baseline"] = (cpu_baseline_train(args.books, args.embed, sd) if train else
+                                        cpu_baseline(args.workload, args.books, args.embed, sd))
                 line["speedup_vs_cpu"] = line["value"] / line["cpu_baseline"]["value"]
             except Exception as ex:       # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "token-frames/s", "cores": torch.get_num_threads(),

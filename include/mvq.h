@@ -233,7 +233,7 @@ int mvq_rowsum_f32(const float* in, float* out, int rows, int cols, int accumula
 /* Training losses: safe_l1, MultiResSTFTLoss, MelCosineLoss of
  * Training/compare_dacvsproposal_5.py:150-211 and their gradient w.r.t. the predicted waveform.  The STFT is a GEMM:
  * frames[n_fft, cols] (windowed, reflect-padded, center=True) times a real DFT basis -> spec[2*fp, cols] on
- * mvq_conv1d_f32 (k = 1), rows [0,f) = Re, rows [fp, fp+f) = Im, f = n_fft/2+1, fp = f rounded up to 8; its gradient is
+ * mvq_conv1d_f32 (k = 1), rows [0,f) = Re, rows [fp, fp+f) = Im, f = n_fft/2+1, fp = f rounded up to 32; its gradient is
  * the transposed GEMM followed by overlap_add.  Column = half*batch*nframes + b*nframes + n, half 0 = prediction,
  * half 1 = target, ncols >= 2*batch*nframes, nframes = 1 + t/hop.  These entry points are the HBM-bound glue:
  *   stft_frames       out[f][col0 + b*nframes + n] = window[f] * finite_or_zero(x[b][reflect(n*hop + f - n_fft/2)])

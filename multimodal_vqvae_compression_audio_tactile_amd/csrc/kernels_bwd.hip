@@ -15,39 +15,58 @@ namespace mvq {
 //   pass 1 (one thread per token): mu, rstd, m1 = mean(g*gamma), m2 = mean(g*gamma*xhat) -> gx ; stats[n] = (mu, rstd)
 //   pass 2 (one block per channel): dgamma[c] += sum_n g*xhat, dbeta[c] += sum_n g       (accumulates into the outputs)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void layernorm_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+// 16 tokens x 16 channel-groups per block: thread (tok, cg) walks channels cg, cg+16, ... of its token; the four
+// per-token reductions (sum, variance, m1, m2) are combined across the 16 groups through LDS.  x and g are re-read from
+// L2 (a block's working set is 2 x 16 x C floats) rather than staged, so any C fits.
+constexpr int LNB_TOK = 16, LNB_CG = 16;
+
+__device__ __forceinline__ float lnb_reduce(float v, float* red, int tok, int cg)
+{
+    __syncthreads();
+    red[cg * LNB_TOK + tok] = v;
+    __syncthreads();
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < LNB_CG; ++k) s += red[k * LNB_TOK + tok];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ pe,
                                        const float* __restrict__ gamma, const float* __restrict__ g,
                                        float* __restrict__ gx, float* __restrict__ stats,
                                        int B, int C, int T, size_t sb, size_t sc, float eps)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= B * T) return;
-    const int b = n / T, t = n - b * T;
+    __shared__ float red[LNB_CG * LNB_TOK];
+    const int tok = threadIdx.x & (LNB_TOK - 1), cg = threadIdx.x / LNB_TOK;
+    const int n = blockIdx.x * LNB_TOK + tok;
+    const bool live = n < B * T;
+    const int b = live ? n / T : 0, t = live ? n - b * T : 0;
     const size_t base = (size_t)b * sb + t;
     const float* per = pe ? pe + (size_t)t * C : nullptr;
     float s = 0.0f;
-    for (int c = 0; c < C; ++c) { float v = x[base + (size_t)c * sc]; if (per) v += per[c]; s += v; }
-    const float mu = s / (float)C;
+    if (live) for (int c = cg; c < C; c += LNB_CG) { float v = x[base + (size_t)c * sc]; if (per) v += per[c]; s += v; }
+    const float mu = lnb_reduce(s, red, tok, cg) / (float)C;
     float var = 0.0f;
-    for (int c = 0; c < C; ++c) { float v = x[base + (size_t)c * sc]; if (per) v += per[c]; const float d = v - mu; var = dfma(d, d, var); }
-    const float rstd = 1.0f / __builtin_sqrtf(var / (float)C + eps);
+    if (live) for (int c = cg; c < C; c += LNB_CG) { float v = x[base + (size_t)c * sc]; if (per) v += per[c]; const float d = v - mu; var = dfma(d, d, var); }
+    const float rstd = 1.0f / __builtin_sqrtf(lnb_reduce(var, red, tok, cg) / (float)C + eps);
     float m1 = 0.0f, m2 = 0.0f;
-    for (int c = 0; c < C; ++c) {
+    if (live) for (int c = cg; c < C; c += LNB_CG) {
         float v = x[base + (size_t)c * sc]; if (per) v += per[c];
-        const float xh = (v - mu) * rstd;
         const float gg = g[base + (size_t)c * sc] * gamma[c];
-        m1 += gg; m2 = dfma(gg, xh, m2);
+        m1 += gg; m2 = dfma(gg, (v - mu) * rstd, m2);
     }
-    m1 /= (float)C; m2 /= (float)C;
+    m1 = lnb_reduce(m1, red, tok, cg) / (float)C;
+    m2 = lnb_reduce(m2, red, tok, cg) / (float)C;
+    if (!live) return;
     if (gx) {
-        for (int c = 0; c < C; ++c) {
+        for (int c = cg; c < C; c += LNB_CG) {
             float v = x[base + (size_t)c * sc]; if (per) v += per[c];
             const float xh = (v - mu) * rstd;
             const float gg = g[base + (size_t)c * sc] * gamma[c];
             gx[base + (size_t)c * sc] = rstd * (gg - m1 - xh * m2);
         }
     }
-    stats[2 * n] = mu; stats[2 * n + 1] = rstd;
+    if (cg == 0) { stats[2 * n] = mu; stats[2 * n + 1] = rstd; }
 }
 
 __global__ __launch_bounds__(256) void layernorm_bwd_param_kernel(
@@ -81,7 +100,7 @@ hipError_t launch_layernorm_bwd(const float* x, const float* pe, const float* ga
 {
     const int n = B * T;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(layernorm_bwd_x_kernel, dim3((n + 63) / 64), dim3(64), 0, s, x, pe, gamma, g, gx, stats, B, C, T, sb, sc, eps);
+    hipLaunchKernelGGL(layernorm_bwd_x_kernel, dim3((n + LNB_TOK - 1) / LNB_TOK), dim3(256), 0, s, x, pe, gamma, g, gx, stats, B, C, T, sb, sc, eps);
     hipLaunchKernelGGL(layernorm_bwd_param_kernel, dim3(C), dim3(256), 0, s, x, pe, g, stats, dgamma, dbeta, B, C, T, sb, sc);
     return hipGetLastError();
 }

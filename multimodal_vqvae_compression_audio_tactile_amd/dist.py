@@ -7,6 +7,12 @@ every rank must apply the SAME update.  ``ema_step_all_ranks`` all-gathers the d
 per rank: ~170 KB at the reference batch of 6 -- latency-bound on xGMI, one collective) in rank order and then runs
 the identical deterministic ``ema_step`` on every rank, which preserves the reference's token-order sums bit for bit
 (an all-reduce of partial sums would change the summation order).
+
+Data-parallel training adds the one collective every DP job has: the gradients of the 21 trainable tensors (8.6 M fp32 =
+34 MB).  ``allreduce_grads`` packs them into ONE flat bucket and issues ONE all-reduce after backward -- on the
+point-to-point xGMI ring that is bandwidth-bound at ~2*(N-1)/N * 34 MB per link (~0.4 ms at 8 ranks), far below the
+~0.5 s step, so finer bucketing / overlap with backward buys nothing here.  Every loss term of the reference is a mean
+over batch items, so the global-batch gradient is sum_r (B_r / B_total) * grad_r; uneven shards are weighted accordingly.
 """
 from __future__ import annotations
 
@@ -54,3 +60,25 @@ def gather_tokens(r_tokens: torch.Tensor, group=None) -> torch.Tensor:
 def ema_step_all_ranks(vq, r_tokens: torch.Tensor, group=None) -> None:
     """Distributed form of `net.vq.ema_step(out["r_tokens"])`: identical codebooks on every rank afterwards."""
     vq.ema_step(gather_tokens(r_tokens, group))
+
+
+def allreduce_grads(params, local_items: int, group=None) -> None:
+    """Make every rank's ``.grad`` the gradient of the GLOBAL-batch mean loss: one flat-bucket all-reduce.
+    Call between ``total.backward()`` and ``clip_grad_norm_`` / ``opt.step()`` (Training/...5.py:393-395)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    params = [p for p in params if p.grad is not None]
+    if not params:
+        return
+    dev = params[0].grad.device
+    n = torch.tensor([float(local_items)], device=dev, dtype=torch.float64)
+    dist.all_reduce(n, group=group)
+    flat = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in params])
+    flat.mul_(float(local_items) / float(n.item()))
+    dist.all_reduce(flat, group=group)
+    off = 0
+    for p in params:
+        k = p.grad.numel()
+        p.grad.copy_(flat[off:off + k].view_as(p.grad))
+        off += k

@@ -42,7 +42,7 @@ class _SpecPlan:
 
     def __init__(self, n_fft, device):
         self.n_fft, self.F = n_fft, n_fft // 2 + 1
-        self.Fp = (self.F + 7) // 8 * 8
+        self.Fp = (self.F + 31) // 32 * 32          # the k = 1 MFMA path wants its reduction dimension in 32s
         k = torch.arange(self.F, dtype=torch.float64).unsqueeze(1)
         f = torch.arange(n_fft, dtype=torch.float64).unsqueeze(0)
         ang = 2.0 * math.pi * ((k * f) % n_fft) / n_fft
@@ -67,7 +67,7 @@ class _MelPlan:
 
     def __init__(self, device, n_fft=MEL_NFFT, n_mels=MEL_MELS, sr=TARGET_SR):
         F = n_fft // 2 + 1
-        Fp = (F + 7) // 8 * 8
+        Fp = (F + 31) // 32 * 32
         W = torch.zeros(n_mels, Fp)
         W[:, :F] = mel_filterbank(F, 0.0, sr * 0.5, n_mels, sr).t()
         W = W.to(device).reshape(n_mels, Fp, 1).contiguous()

@@ -416,14 +416,14 @@ def rowsum(x):
 
 def linear_wgrad(g, x):
     """dW[O,I] = g[O,N] x[I,N]^T over the token axis N, as a k=1 conv on the MFMA kernel with K = tokens:
-    packed 'weights' = g^T (K-major), input = x^T [N, I].  N is padded with zero tokens to a multiple of 8."""
+    packed 'weights' = g^T (K-major), input = x^T [N, I].  N is padded with zero tokens to a multiple of 32."""
     g = _dev(g, "g"); x = _dev(x, "x")
     O, N = g.shape
     I, N2 = x.shape
     if N != N2:
         raise MvqError("linear_wgrad: token counts differ")
-    if N % 8:
-        padn = 8 - N % 8
+    if N % 32:
+        padn = 32 - N % 32
         g = torch.nn.functional.pad(g, (0, padn)); x = torch.nn.functional.pad(x, (0, padn)); N += padn
     wp = pack_conv1d(g.reshape(O, N, 1))
     xt = transpose2d(x).reshape(1, N, I)

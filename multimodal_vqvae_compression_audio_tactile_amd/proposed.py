@@ -176,13 +176,16 @@ class _ProposedBase(nn.Module):
         self._pd, self._pu = _PackedLinear(self.proj_down), _PackedLinear(self.proj_up)
         self._scale_host = None
 
-    def _scale_value(self) -> float:
-        """clamp(scale, 5e-3, 0.5) as a host float (one device read, cached per parameter version)."""
+    def _scale_raw(self) -> float:
+        """The scale parameter as a host float (one device read, cached per parameter version)."""
         key = (self.scale._version, self.scale.data_ptr())
         if self._scale_host is None or self._scale_host[0] != key:
-            v = float(self.scale.detach().float().clamp(5e-3, 0.5).item())
-            self._scale_host = (key, v)
+            self._scale_host = (key, float(self.scale.detach().float().item()))
         return self._scale_host[1]
+
+    def _scale_value(self) -> float:
+        """clamp(scale, 5e-3, 0.5)   (Training/compare_dacvsproposal_5.py:314)."""
+        return min(max(self._scale_raw(), 5e-3), 0.5)
 
     @torch.no_grad()
     def _ar_latents(self, qa, zt, books_use=None, want_tokens=False, tactile_only=False):
@@ -225,6 +228,7 @@ class _ProposedBase(nn.Module):
         B, C, Tlat = zt.shape
         dev = zt.device
         ln = self.tokennorm.ln
+        scale_raw = self._scale_raw()
         chunks, r_toks, prev = [], [], None
         for s in range(0, Tlat, AR_CHUNK_TOK):
             e = min(Tlat, s + AR_CHUNK_TOK)
@@ -240,7 +244,7 @@ class _ProposedBase(nn.Module):
             z_pred = self.predict.run_train(zt_prev, qa_c, B)
             r = ops.sub(zt_c, z_pred.detach())
             u = train.LayerNormC.apply(r, ln.weight, ln.bias, None, ln.eps, B)
-            rN = train.ScaleTanh.apply(u, self.scale)
+            rN = train.ScaleTanh.apply(u, self.scale, scale_raw)
             rD = train.Linear.apply(rN, self.proj_down.weight, self.proj_down.bias, None, self._pd)
             qD = train.RvqSte.apply(rD, self.vq.stacked(), None)
             z_hat = train.Linear.apply(qD, self.proj_up.weight, self.proj_up.bias, z_pred, self._pu)

@@ -116,8 +116,9 @@ class ScaleTanh(Function):
     LO, HI = 5e-3, 0.5
 
     @staticmethod
-    def forward(ctx, u, scale):
-        raw = float(scale.detach().float().item())
+    def forward(ctx, u, scale, raw=None):
+        if raw is None:                                   # one device read; callers in a loop pass the cached host value
+            raw = float(scale.detach().float().item())
         s = min(max(raw, ScaleTanh.LO), ScaleTanh.HI)
         ctx.save_for_backward(u)
         ctx.s, ctx.inside = s, (ScaleTanh.LO <= raw <= ScaleTanh.HI)
@@ -129,7 +130,7 @@ class ScaleTanh(Function):
         gu, ds = ops.scale_tanh_bwd(u.detach(), _c(g), ctx.s)
         if not ctx.inside:
             ds = torch.zeros_like(ds)
-        return gu, ds
+        return gu, ds, None
 
 
 class RvqSte(Function):

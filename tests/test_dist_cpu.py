@@ -55,6 +55,37 @@ def test_ema_update_identical_on_all_ranks(tmp_path, orc):
     assert np.array_equal(np.load(tmp_path / "tok_0.npy"), z) and np.array_equal(np.load(tmp_path / "tok_1.npy"), z)
 
 
+def _grad_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from multimodal_vqvae_compression_audio_tactile_amd import dist as mdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(5, 3)); b = torch.nn.Parameter(torch.randn(5)); unused = torch.nn.Parameter(torch.zeros(2))
+    x = torch.randn(7, 3, generator=torch.Generator().manual_seed(1))
+    s, e = mdist.shard_range(7, rank, world)                 # 4 + 3 items
+    loss = ((x[s:e] @ w.t() + b) ** 2).mean(dim=1).mean()    # a per-item mean, like every term of the reference's loss
+    loss.backward()
+    mdist.allreduce_grads([w, b, unused], e - s)
+    torch.save({"w": w.grad, "b": b.grad, "unused": unused.grad}, os.path.join(out_dir, f"g_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_equals_global_batch(tmp_path):
+    world = 2
+    mp.start_processes(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(5, 3)); b = torch.nn.Parameter(torch.randn(5))
+    x = torch.randn(7, 3, generator=torch.Generator().manual_seed(1))
+    with torch.enable_grad():
+        ((x @ w.t() + b) ** 2).mean(dim=1).mean().backward()
+    g0, g1 = torch.load(tmp_path / "g_0.pt"), torch.load(tmp_path / "g_1.pt")
+    assert torch.equal(g0["w"], g1["w"]) and torch.equal(g0["b"], g1["b"]) and g0["unused"] is None
+    assert torch.allclose(g0["w"], w.grad, rtol=1e-5, atol=1e-7) and torch.allclose(g0["b"], b.grad, rtol=1e-5, atol=1e-7)
+
+
 def test_sharding_covers_every_segment_once():
     from multimodal_vqvae_compression_audio_tactile_amd import dist as mdist
     for n in (0, 1, 7, 8, 1003):
