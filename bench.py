@@ -245,8 +245,8 @@ def main():
     torch.cuda.synchronize()
 
     kev = None
-    if not args.no_kernel_events:
-        kev = KernelEvents(); kev.wrap(ops)
+    if not args.no_kernel_events and not train:           # the train step has ~600 small launches: the per-launch host cost
+        kev = KernelEvents(); kev.wrap(ops)               # of the event wrappers would be what gets measured
 
     if dist: dist.barrier()
     torch.cuda.synchronize()
