@@ -246,7 +246,9 @@ int mvq_rowsum_f32(const float* in, float* out, int rows, int cols, int accumula
  *   l1_loss           partial[p] block sums of |y - tgt| (finite_or_zero applied); dy += coef*sign(y - tgt) if dy
  *   mel_max / mel_cos / mel_max_grad : per-item max of the mel spectrogram (MelCosineLoss._mel_mag's amax), the per-frame
  *                     cosine of log(M/max + eps) and its gradient w.r.t. the prediction's mel magnitudes (dmel[n_mels]
- *                     [batch*nframes], dden per column; mel_max_grad routes the max's gradient to its argmax element)
+ *                     [batch*nframes], dden per column; mel_max_grad routes the max's gradient to its argmax element);
+ *                     use_log = 0 gives the cosine of the max-normalised LINEAR mel frames = stsim_batch
+ *                     (Evaluation/compare_dacvsproposal_5_eval.py:142-177; forward only)
  * Checked against torch autograd on the restated losses and fixture G7 (fp32 tolerance). */
 int mvq_stft_frames_f32(const float* x, const float* window, float* out, int batch, int t, int n_fft, int hop, int nframes,
                         size_t ncols, size_t col0, void* stream);
@@ -259,9 +261,17 @@ int mvq_overlap_add_f32(const float* dframes, const float* window, float* dy, in
 int mvq_l1_loss_f32(const float* y, const float* tgt, float* partial, int p, float* dy, float coef, size_t n, void* stream);
 int mvq_mel_max_f32(const float* mel, float* maxv, int* argmax, int n_mels, int batch, int nframes, size_t ncols, void* stream);
 int mvq_mel_cos_f32(const float* mel, const float* maxv, float* cosv, float* dmel, float* dden, float coef, int n_mels, int batch,
-                    int nframes, size_t ncols, float eps, void* stream);
+                    int nframes, size_t ncols, float eps, int use_log, void* stream);
 int mvq_mel_max_grad_f32(const float* dden, const float* maxv, const int* argmax, float* dmel, int batch, int nframes, float eps,
                          void* stream);
+
+/* Polyphase sinc resampler: torchaudio.transforms.Resample(orig, new) as the reference
+ * calls it on every file (Training/compare_dacvsproposal_5.py:110-113, Evaluation/dac_vcpwq_proposed6_latency.py:151-156).
+ * orig/newf are the rates divided by their gcd, kern[newf][ks] the filter bank (ks = 2*width + orig),
+ * y[b][n*newf + p] = sum_k kern[p][k] * xpad[b][n*orig + k] with x zero-padded by `width` on the left,
+ * len_out <= ceil(newf*len/orig).  One fp32 fma chain per output sample, k ascending (bit-exact vs the oracle). */
+int mvq_resample_f32(const float* x, const float* kern, float* y, int batch, int len, int len_out, int orig, int newf,
+                     int width, int ks, void* stream);
 
 /* out = g * (1 - y*y): backward of the decoder's final tanh (y = saved output). */
 int mvq_mul_dtanh_f32(const float* g, const float* y, float* out, size_t n, void* stream);

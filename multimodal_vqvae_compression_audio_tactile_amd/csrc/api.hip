@@ -535,16 +535,28 @@ int mvq_mel_max_f32(const float* mel, float* maxv, int* argmax, int n_mels, int 
                   mvq::launch_mel_max(mel, maxv, argmax, n_mels, batch, nframes, ncols, S(stream)));
 }
 int mvq_mel_cos_f32(const float* mel, const float* maxv, float* cosv, float* dmel, float* dden, float coef, int n_mels, int batch,
-                    int nframes, size_t ncols, float eps, void* stream)
+                    int nframes, size_t ncols, float eps, int use_log, void* stream)
 {
-    MVQ_LOSS_CALL(!mel || !maxv || !cosv || (dmel && !dden) || n_mels <= 0 || batch < 0 || (size_t)2 * batch * nframes > ncols, "mel_cos",
-                  mvq::launch_mel_cos(mel, maxv, cosv, dmel, dden, coef, n_mels, batch, nframes, ncols, eps, S(stream)));
+    MVQ_LOSS_CALL(!mel || !maxv || !cosv || (dmel && (!dden || !use_log)) || n_mels <= 0 || batch < 0 || (size_t)2 * batch * nframes > ncols, "mel_cos",
+                  mvq::launch_mel_cos(mel, maxv, cosv, dmel, dden, coef, n_mels, batch, nframes, ncols, eps, use_log, S(stream)));
 }
 int mvq_mel_max_grad_f32(const float* dden, const float* maxv, const int* argmax, float* dmel, int batch, int nframes, float eps,
                          void* stream)
 {
     MVQ_LOSS_CALL(!dden || !maxv || !argmax || !dmel || batch < 0, "mel_max_grad",
                   mvq::launch_mel_max_grad(dden, maxv, argmax, dmel, batch, nframes, eps, S(stream)));
+}
+
+int mvq_resample_f32(const float* x, const float* kern, float* y, int batch, int len, int len_out, int orig, int newf,
+                     int width, int ks, void* stream)
+{
+    if (batch < 0 || len < 0 || len_out < 0 || orig <= 0 || newf <= 0 || width < 0 || ks != 2 * width + orig)
+        return fail(MVQ_EINVAL, "resample: bad shape (ks must be 2*width + orig)");
+    if ((long long)len_out > ((long long)newf * len + orig - 1) / orig) return fail(MVQ_EINVAL, "resample: len_out exceeds ceil(new*len/orig)");
+    if (batch == 0 || len_out == 0) return MVQ_OK;
+    if (!x || !kern || !y) return fail(MVQ_EINVAL, "resample: null tensor");
+    hipError_t e = mvq::launch_resample(x, kern, y, batch, len, len_out, orig, newf, width, ks, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "resample");
 }
 
 int mvq_mul_dtanh_f32(const float* g, const float* y, float* out, size_t n, void* stream)

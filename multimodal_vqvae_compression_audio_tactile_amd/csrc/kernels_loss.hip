@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void mel_max_kernel(const float* __restrict__ 
 // constant) and dden[c] = this column's share of dL/d(denx); coef = dL/dcos (same for every column).
 __global__ __launch_bounds__(256) void mel_cos_kernel(const float* __restrict__ M, const float* __restrict__ maxv,
                                                       float* __restrict__ cosv, float* __restrict__ dM, float* __restrict__ dden,
-                                                      float coef, int n_mels, int B, int nframes, size_t ncols, float eps)
+                                                      float coef, int n_mels, int B, int nframes, size_t ncols, float eps,
+                                                      int use_log)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int half = B * nframes;
@@ -187,14 +188,15 @@ __global__ __launch_bounds__(256) void mel_cos_kernel(const float* __restrict__ 
     const float denx = __builtin_fmaxf(maxv[b], eps), deny = __builtin_fmaxf(maxv[B + b], eps);
     float num = 0.0f, nx = 0.0f, ny = 0.0f;
     for (int m = 0; m < n_mels; ++m) {
-        const float X = logf(M[(size_t)m * ncols + c] / denx + eps), Y = logf(M[(size_t)m * ncols + half + c] / deny + eps);
+        float X = M[(size_t)m * ncols + c] / denx, Y = M[(size_t)m * ncols + half + c] / deny;
+        if (use_log) { X = logf(X + eps); Y = logf(Y + eps); }              // MelCosineLoss; linear = stsim_batch
         num += X * Y; nx += X * X; ny += Y * Y;
     }
     nx = __builtin_sqrtf(nx); ny = __builtin_sqrtf(ny);
     const float prod = nx * ny, den2 = __builtin_fmaxf(prod, eps);
     const float v = num / den2;
     cosv[c] = __builtin_fminf(__builtin_fmaxf(v, -1.0f), 1.0f);
-    if (!dM) return;
+    if (!dM || !use_log) return;
     const float gv = (v >= -1.0f && v <= 1.0f) ? coef : 0.0f;          // clamp(-1, 1) passes the gradient inside the range
     const float gnum = gv / den2;
     const float gprod = (prod >= eps) ? -gv * num / (den2 * den2) : 0.0f;
@@ -275,10 +277,10 @@ hipError_t launch_mel_max(const float* M, float* maxv, int* argm, int n_mels, in
     return hipGetLastError();
 }
 hipError_t launch_mel_cos(const float* M, const float* maxv, float* cosv, float* dM, float* dden, float coef, int n_mels, int B,
-                          int nframes, size_t ncols, float eps, hipStream_t s)
+                          int nframes, size_t ncols, float eps, int use_log, hipStream_t s)
 {
     if (B * nframes == 0) return hipSuccess;
-    hipLaunchKernelGGL(mel_cos_kernel, dim3((B * nframes + 255) / 256), dim3(256), 0, s, M, maxv, cosv, dM, dden, coef, n_mels, B, nframes, ncols, eps);
+    hipLaunchKernelGGL(mel_cos_kernel, dim3((B * nframes + 255) / 256), dim3(256), 0, s, M, maxv, cosv, dM, dden, coef, n_mels, B, nframes, ncols, eps, use_log);
     return hipGetLastError();
 }
 hipError_t launch_mel_max_grad(const float* dden, const float* maxv, const int* argm, float* dM, int B, int nframes, float eps, hipStream_t s)

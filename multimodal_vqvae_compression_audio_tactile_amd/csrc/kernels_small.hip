@@ -615,4 +615,44 @@ hipError_t launch_align_xcorr(const float* r, const float* e, int T, int max_shi
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// polyphase sinc resampler (torchaudio.transforms.Resample as the reference uses it, Training/compare_dacvsproposal_5.py:
+// 110-113): y[b][n*newf + p] = sum_k kern[p][k] * xpad[b][n*orig + k], xpad = x zero-padded by `width` on the left.
+// HBM-bound (L in, Lout out); the [newf][ks] filter bank sits in LDS when it fits.  One fma chain per output, k ascending.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, const float* __restrict__ kern,
+                                                       float* __restrict__ y, int L, int Lout, int orig, int newf,
+                                                       int width, int ks, int kern_in_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) float ksm[];
+    if (kern_in_lds) {
+        for (int e = threadIdx.x; e < newf * ks; e += 256) ksm[e] = kern[e];
+        __syncthreads();
+    }
+    const float* kt = kern_in_lds ? ksm : kern;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= Lout) return;
+    const int b = blockIdx.y;
+    const int n = m / newf, p = m - n * newf;
+    const float* xb = x + (size_t)b * L;
+    const float* kp = kt + (size_t)p * ks;
+    const int j0 = n * orig - width;
+    int k_lo = j0 < 0 ? -j0 : 0;
+    int k_hi = ks; if (j0 + k_hi > L) k_hi = L - j0;
+    float acc = 0.0f;
+    for (int k = k_lo; k < k_hi; ++k) acc = dfma(kp[k], xb[j0 + k], acc);
+    y[(size_t)b * Lout + m] = acc;
+}
+
+hipError_t launch_resample(const float* x, const float* kern, float* y, int B, int L, int Lout, int orig, int newf,
+                           int width, int ks, hipStream_t s)
+{
+    if (B == 0 || Lout == 0) return hipSuccess;
+    const size_t lds = (size_t)newf * ks * sizeof(float);
+    const int in_lds = lds <= 64 * 1024;
+    hipLaunchKernelGGL(resample_kernel, dim3((Lout + 255) / 256, B), dim3(256), in_lds ? lds : 0, s, x, kern, y, L, Lout,
+                       orig, newf, width, ks, in_lds);
+    return hipGetLastError();
+}
+
 }  // namespace mvq

@@ -54,8 +54,10 @@ hipError_t launch_overlap_add(const float* dF, const float* window, float* dy, i
 hipError_t launch_l1_loss(const float* y, const float* tgt, float* partial, int P, float* dy, float coef, size_t n, hipStream_t s);
 hipError_t launch_mel_max(const float* M, float* maxv, int* argm, int n_mels, int B, int nframes, size_t ncols, hipStream_t s);
 hipError_t launch_mel_cos(const float* M, const float* maxv, float* cosv, float* dM, float* dden, float coef, int n_mels, int B,
-                          int nframes, size_t ncols, float eps, hipStream_t s);
+                          int nframes, size_t ncols, float eps, int use_log, hipStream_t s);
 hipError_t launch_mel_max_grad(const float* dden, const float* maxv, const int* argm, float* dM, int B, int nframes, float eps, hipStream_t s);
+hipError_t launch_resample(const float* x, const float* kern, float* y, int B, int L, int Lout, int orig, int newf,
+                           int width, int ks, hipStream_t s);
 hipError_t launch_align_xcorr(const float* r, const float* e, int T, int max_shift, float* corr, int* scratch_valid,
                               int* best_shift, hipStream_t s);
 

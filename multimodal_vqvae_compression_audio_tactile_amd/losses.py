@@ -231,3 +231,21 @@ class TrainingLoss(nn.Module):
     def forward(self, y, tgt):
         total, self.parts = _evaluate(y, tgt, *self.w)
         return total
+
+
+@torch.no_grad()
+def stsim_batch(ref_1T, est_1T):
+    """Spectro-temporal similarity per item (Evaluation/compare_dacvsproposal_5_eval.py:142-177): 0.5*(1 + mean over
+    frames of the cosine between the max-normalised 64-band HTK mel magnitudes, n_fft 512, hop 128).  Returns a list of
+    floats like the reference (one device->host copy).  Inputs of equal length (the reference crops them first)."""
+    r, e = _prep(ref_1T), _prep(est_1T)
+    if r.shape != e.shape:
+        raise ops.MvqError("stsim_batch: crop_match the signals first (equal lengths)")
+    eps = 1e-8
+    sp = _Spectra(r, e, MEL_NFFT, MEL_HOP, eps)
+    mp = _MelPlan.get(r.device)
+    M = ops.conv1d(sp.mag.reshape(1, mp.Fp, 2 * sp.Nh), mp.wp, mp.n_mels, 1)
+    maxv, _ = ops.mel_max(M, mp.n_mels, sp.B, sp.nfr)
+    cosv, _, _ = ops.mel_cos(M, maxv, mp.n_mels, sp.B, sp.nfr, eps, use_log=False)
+    mean_cos = ops.rowsum(cosv.reshape(sp.B, sp.nfr)) / float(sp.nfr)
+    return [float(v) for v in (0.5 * (mean_cos + 1.0)).cpu()]

@@ -487,13 +487,14 @@ def mel_max(M, n_mels, B, nfr):
     return maxv, argm
 
 
-def mel_cos(M, maxv, n_mels, B, nfr, eps, coef=None):
+def mel_cos(M, maxv, n_mels, B, nfr, eps, coef=None, use_log=True):
     """-> cos[B*nfr] (, dM[n_mels, B*nfr], dden[B*nfr] when coef = dL/dcos is given)."""
     cosv = torch.empty(B * nfr, device=M.device, dtype=torch.float32)
     dM = torch.empty(n_mels, B * nfr, device=M.device, dtype=torch.float32) if coef is not None else None
     dden = torch.empty(B * nfr, device=M.device, dtype=torch.float32) if coef is not None else None
     check(_lib.lib().mvq_mel_cos_f32(M.data_ptr(), maxv.data_ptr(), cosv.data_ptr(), _p(dM), _p(dden),
-                                     float(coef or 0.0), n_mels, B, nfr, M.shape[-1], float(eps), _stream()), "mvq_mel_cos_f32")
+                                     float(coef or 0.0), n_mels, B, nfr, M.shape[-1], float(eps), int(use_log), _stream()),
+          "mvq_mel_cos_f32")
     return cosv, dM, dden
 
 

@@ -532,3 +532,23 @@ void orc_mul_dtanh(const float* g, const float* y, float* out, size_t n)
 {
     for (size_t i = 0; i < n; ++i) out[i] = g[i] * om_fma(-y[i], y[i], 1.0f);
 }
+
+
+/* ---- polyphase sinc resampler (row f3) ----------------------------------------------------------------------------
+ * torchaudio.transforms.Resample as the reference calls it (Training/compare_dacvsproposal_5.py:110-113,
+ * Evaluation/dac_vcpwq_proposed6_latency.py:151-156): y[n*newf + p] = sum_k kern[p][k] * xpad[n*orig + k], xpad = x
+ * zero-padded by `width` on the left; one fp32 fma chain per output, k ascending.  kern[newf][ks] comes from
+ * oracle.py:resample_kernel (float64 design, rounded to fp32). */
+void orc_resample(const float* x, const float* kern, float* y, int B, int L, int Lout, int orig, int newf, int width, int ks)
+{
+    for (int b = 0; b < B; ++b)
+        for (int m = 0; m < Lout; ++m) {
+            const int n = m / newf, p = m - n * newf;
+            float acc = 0.0f;
+            for (int k = 0; k < ks; ++k) {
+                const int j = n * orig + k - width;
+                if (j >= 0 && j < L) acc = om_fma(kern[(size_t)p * ks + k], x[(size_t)b * L + j], acc);
+            }
+            y[(size_t)b * Lout + m] = acc;
+        }
+}

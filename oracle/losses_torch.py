@@ -91,3 +91,20 @@ def melcos(x, y, fb=None, eps=1e-7):
 def total_loss(y, tgt):
     l1, st, me = safe_l1(y, tgt), mrstft(y, tgt), melcos(y, tgt)
     return W_WAV_L1 * l1 + W_STFT * st + W_MELCOS * me, (l1, st, me)
+
+
+@torch.no_grad()
+def stsim_batch(ref_1T, est_1T, fb=None):
+    """Evaluation/compare_dacvsproposal_5_eval.py:142-177 (equal-length inputs: no interpolation branch)."""
+    fb = mel_filterbank() if fb is None else fb
+
+    def mel_mag(x):
+        x = x[:, 0, :] if x.dim() == 3 else x
+        mag = stft_mag(x, 512, 128, 512, 1e-8)
+        M = torch.matmul(mag.transpose(-1, -2), fb).transpose(-1, -2)
+        return M / M.amax(dim=(1, 2), keepdim=True).clamp_min(1e-8)
+
+    R, E = mel_mag(ref_1T), mel_mag(est_1T)
+    num = (R * E).sum(dim=1)
+    den = (R.norm(dim=1) * E.norm(dim=1)).clamp_min(1e-8)
+    return [float(v) for v in 0.5 * ((num / den).clamp(-1, 1).mean(dim=-1) + 1.0)]

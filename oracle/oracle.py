@@ -499,3 +499,44 @@ def dac_decoder_backward_input(sd, saved, gy, rates=DEC_RATES, prefix=""):
         g = mul_dsnake(conv_transpose1d_dgrad(g, w, s, math.ceil(s / 2)), saved[f"b{i}.x"], sd[p + ".block.0.alpha"])
     w, _ = _wn(sd, P + "model.0")
     return conv1d_dgrad(g, w, 1, 3)
+
+
+# ------------------------------------------------------------------------------------- resampler (row f3)
+def resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """torchaudio's default ``sinc_interp_hann`` kernel (torchaudio.functional.functional._get_sinc_resample_kernel),
+    restated from the published algorithm -- torchaudio is absent from this image, so this row is PARITY UNPINNED
+    against torchaudio itself and is validated by signal properties (tests/test_oracle_resample.py):
+      g = gcd; orig, new = f/g; base = min(orig, new)*rolloff; width = ceil(lpw*orig/base)
+      t[p][k] = (-p/new + (k - width)/orig) * base, clamped to [-lpw, lpw]
+      kern[p][k] = sinc(pi t) * cos(pi t / (2 lpw))^2 * base/orig        (float64, then rounded to fp32)
+    -> (kern[new, 2*width+orig] float32, width, orig, new)."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base = min(orig, new) * rolloff
+    width = int(math.ceil(lowpass_filter_width * orig / base))
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = (np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx) * base
+    t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    with np.errstate(invalid="ignore", divide="ignore"):
+        kern = np.where(t == 0, 1.0, np.sin(t) / t) * window * (base / orig)
+    return kern.astype(np.float32), width, orig, new
+
+
+def resample(x, orig_freq: int, new_freq: int, kern=None):
+    """x[..., L] -> [..., ceil(new*L/orig)]  (identity when the rates are equal, as the reference short-circuits).
+    ``kern``: use this filter bank instead of the oracle's own design (to compare the convolution alone)."""
+    if int(orig_freq) == int(new_freq):
+        return np.asarray(x, np.float32)
+    kern0, width, orig, new = resample_kernel(orig_freq, new_freq)
+    kern = kern0 if kern is None else np.ascontiguousarray(kern, np.float32)
+    assert kern.shape == kern0.shape
+    x_, xp = _f(x)
+    lead, L = x_.shape[:-1], x_.shape[-1]
+    B = int(np.prod(lead)) if lead else 1
+    Lout = int(math.ceil(new * L / orig))
+    y = np.empty((B, Lout), np.float32)
+    k_, kp = _f(kern)
+    lib().orc_resample(xp, kp, y.ctypes.data_as(f32p), B, L, Lout, orig, new, width, kern.shape[1])
+    return y.reshape(lead + (Lout,))

@@ -17,6 +17,7 @@ patched) and records inputs-by-seed + expected outputs of:
      oracle/losses_torch.MelScale because torchaudio is absent), total = .55/.25/.20 mix, autograd backward (eval mode:
      dropout off; fp32, no autocast).  Stored: the losses, y_hat, dL/dy_hat and for every trainable tensor its norm
      and the subsample flat[::997].
+  G8 stsim_batch (Evaluation/compare_dacvsproposal_5_eval.py:142-177), MelScale stand-in as in G7
   G5 psnr_batch / psnr_global_peak_db (Evaluation/compare_dacvsproposal_5_eval.py:180-185, ...6_latency.py:204-214)
 Only data is stored (arrays), never reference source.  Inputs are re-created from seeds by tests/golden_inputs.py.
 """
@@ -146,6 +147,10 @@ def main():
             g7[f"sub.{name}"] = p_.grad.reshape(-1)[::gi.GRAD_STRIDE].numpy().copy()
     assert all(p_.grad is None for n_, p_ in net.named_parameters() if n_.split(".")[0] in ("A_ENC", "A_QUANT", "T_ENC", "T_DEC"))
     np.savez_compressed(OUT / "g7_train_step.npz", **g7)
+    # ---- G8: stsim_batch from the reference function
+    e5.torchaudio.transforms.MelScale = LT.MelScale
+    ref, est = gi.stsim_inputs()
+    np.savez_compressed(OUT / "g8_stsim.npz", stsim=np.array(e5.stsim_batch(ref, est), np.float64))
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size // 1024, "KiB")
 

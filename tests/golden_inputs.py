@@ -73,3 +73,14 @@ def align_inputs(T, shift, noise, seed):
     ref = base[300:300 + T].copy()
     est = base[300 - shift:300 - shift + T] + noise * r.standard_normal(T).astype(np.float32)
     return ref[None].astype(np.float32), est[None].astype(np.float32)
+
+
+def stsim_inputs():
+    """Reference / estimate pairs for stsim_batch: tactile-like segments with a -60 dB floor, estimate = ref + noise of
+    growing level per item (so the values spread over (0.5, 1))."""
+    import torch
+    from multimodal_vqvae_compression_audio_tactile_amd import synth
+    g = torch.Generator().manual_seed(808)
+    ref = synth.tactile_segments(4, seed=8, T=12000) + 1e-3 * torch.randn(4, 1, 12000, generator=g)
+    lvl = torch.tensor([0.0, 0.01, 0.1, 0.5]).reshape(4, 1, 1)
+    return ref, ref + lvl * torch.randn(4, 1, 12000, generator=g)

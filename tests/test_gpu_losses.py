@@ -85,3 +85,14 @@ def test_non_finite_samples_are_zeroed(dev):
     assert abs(float(losses.safe_l1(y.to(dev), tgt.to(dev))) - float(LT.safe_l1(y, tgt))) < 1e-7
     want = float(LT.mrstft(y, tgt))
     assert abs(float(losses.MultiResSTFTLoss()(y.to(dev), tgt.to(dev))) - want) <= 1e-4 * want
+
+
+def test_stsim_batch(dev):
+    """Row f4: stsim_batch on HIP vs the reference function's fixture (G8) and the restatement."""
+    from oracle import losses_torch as LT
+    from multimodal_vqvae_compression_audio_tactile_amd import stsim_batch
+    G8 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_stsim.npz"))
+    ref, est = gi.stsim_inputs()
+    got = stsim_batch(ref.to(dev), est.to(dev))
+    assert np.allclose(got, G8["stsim"], rtol=0, atol=2e-5), (got, G8["stsim"])
+    assert np.allclose(got, LT.stsim_batch(ref, est), rtol=0, atol=2e-5)

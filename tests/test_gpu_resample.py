@@ -1,0 +1,30 @@
+"""-m gpu: the polyphase resampler on HIP (row f3) bit-exact against the oracle's convolution (same fma order), for the rate
+pairs the reference meets (44.1 kHz audio, 2.8 / 3 kHz tactile <-> the 24 kHz model rate)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("fi,fo,shape", [(44100, 24000, (1, 44100)), (3000, 24000, (2, 1, 3000)), (2800, 24000, (1, 2800 * 2 + 13)),
+                                          (24000, 3000, (3, 24000)), (48000, 24000, (1, 1, 999)), (44100, 24000, (1, 5))])
+def test_resample_bit_exact(fi, fo, shape, orc, dev):
+    from multimodal_vqvae_compression_audio_tactile_amd import Resample, resample_to
+    r = np.random.default_rng(fi + fo + shape[-1])
+    x = r.uniform(-1, 1, shape).astype(np.float32)
+    mod = Resample(fi, fo).to(dev)
+    y = mod(torch.from_numpy(x).to(dev))
+    want = orc.resample(x, fi, fo, kern=mod.kernel.cpu().numpy())
+    assert y.shape == want.shape
+    assert np.array_equal(y.cpu().numpy(), want)
+    own = orc.resample(x, fi, fo)                                  # oracle's own (numpy) filter design
+    assert np.allclose(y.cpu().numpy(), own, rtol=0, atol=2e-6)
+    assert torch.equal(resample_to(torch.from_numpy(x).to(dev), fi, fo), y)
+
+
+def test_resample_identity_and_empty(dev):
+    from multimodal_vqvae_compression_audio_tactile_amd import Resample, resample_to
+    x = torch.randn(1, 100, device=dev)
+    assert resample_to(x, 24000, 24000) is x
+    assert Resample(3000, 24000).to(dev)(torch.zeros(1, 0, device=dev)).shape == (1, 0)

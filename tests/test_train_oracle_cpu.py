@@ -60,3 +60,11 @@ def test_mel_filterbank_properties():
     assert torch.allclose(inner, torch.ones_like(inner), atol=1e-4)
     peak_bin = fb.argmax(dim=0).numpy() * (12000 / 256)
     assert np.all(np.abs(peak_bin - centre) <= 12000 / 256)
+
+
+def test_restated_stsim_matches_reference_fixture():
+    G8 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_stsim.npz"))
+    ref, est = gi.stsim_inputs()
+    got = LT.stsim_batch(ref, est)
+    assert np.allclose(got, G8["stsim"], rtol=1e-6)
+    assert got[0] > 0.999999 and got[0] > got[1] > got[2] > got[3] > 0.5
