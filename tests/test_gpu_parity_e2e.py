@@ -81,11 +81,14 @@ def test_proposed_tactile_only_and_forward_step(orc, dev):
     want = orc.proposed_forward_eval(sdn, None, t.numpy(), tactile_only=True)
     assert np.array_equal(y.cpu().numpy(), want)
     tr = build_proposed(sd, rvq_books=3, rvq_embed=512, device=dev, cls=AllPredAR)
-    out = tr.forward_step(a.to(dev), t.to(dev))
     wz, aux = orc.proposed_encode_latents(sdn, a.numpy(), t.numpy(), return_aux=True)
-    assert np.array_equal(out["r_tokens"].cpu().numpy(), aux["r_tokens"])
     wy = orc.dac_decoder(sdn, wz, prefix="T_DEC.")
-    assert np.array_equal(out["y_hat"].cpu().numpy(), wy[..., :out["y_hat"].shape[-1]])
+    for grad in (False, True):                      # validation (fused inference path) and training (autograd graph) forward
+        with torch.set_grad_enabled(grad):
+            out = tr.forward_step(a.to(dev), t.to(dev))
+        assert out["y_hat"].requires_grad == grad
+        assert np.array_equal(out["r_tokens"].cpu().numpy(), aux["r_tokens"])
+        assert np.array_equal(out["y_hat"].detach().cpu().numpy(), wy[..., :out["y_hat"].shape[-1]])
 
 
 def test_whole_file_audio_shorter_than_tactile(orc, dev):

@@ -5,7 +5,12 @@ import numpy as np
 import pytest
 import torch
 
-torch.set_grad_enabled(False)
+
+
+@pytest.fixture(autouse=True)
+def _no_grad():                      # scoped to this module's tests (a module-level set_grad_enabled would leak into others)
+    with torch.no_grad():
+        yield
 
 
 def test_det_math_accuracy(orc):
