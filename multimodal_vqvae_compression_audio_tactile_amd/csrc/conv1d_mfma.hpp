@@ -41,6 +41,8 @@ struct ConvArgs {
     int Mrows;              // valid GEMM rows (Cout, or Cout*S for UPS)
     int Ncols;              // GEMM columns per batch element (Tout, or Tin+1 for UPS)
     int n_tiles;            // ceil(Ncols / BN)
+    int row_fast;           // 0: grid (column tiles, row tiles).  R > 0: 1-D grid, XCD-aware: the R row tiles of a column
+                            // tile are consecutive on ONE XCD (workgroup id mod 8), so the x tile is fetched into that L2 once
     int act;
     int up_s, up_p;         // UPS: stride S and torch padding P
     int vec4;               // input rows are 16-byte aligned (Tin % 4 == 0 and x 16-byte aligned)
@@ -204,10 +206,17 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     const int l31 = lane & 31;
     const int h = lane >> 5;
 
-    const int b = blockIdx.x / a.n_tiles;
-    const int tile_n = blockIdx.x - b * a.n_tiles;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.row_fast) {
+        const int xcd = bx & 7, j = bx >> 3;
+        by = j % a.row_fast;
+        bx = (j / a.row_fast) * 8 + xcd;
+        if (bx >= a.n_tiles * a.B) return;           // padding blocks of the last group of 8 column tiles
+    }
+    const int b = bx / a.n_tiles;
+    const int tile_n = bx - b * a.n_tiles;
     const int n0 = tile_n * C::BN;
-    const int m0 = blockIdx.y * C::BM;
+    const int m0 = by * C::BM;
     const int t_in0 = n0 * STRIDE - a.pad;           // input sample of tile column 0
     const int g_al = t_in0 & ~3;                     // 16-byte aligned start (floor, also for negatives)
     const int shift = VEC ? (t_in0 - g_al) : 0;      // LDS column of tile column 0
@@ -575,7 +584,17 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
         attr_set = true;
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    dim3 grid((unsigned)(a.n_tiles * a.B), (unsigned)((a.Mrows + C::BM - 1) / C::BM));
+    const unsigned gx = (unsigned)(a.n_tiles * a.B), R = (unsigned)((a.Mrows + C::BM - 1) / C::BM);
+    dim3 grid(gx, R);
+    // Row tiles share the input tile, column tiles share the weight rows.  Default order (row tile slowest) keeps ONE
+    // weight row tile hot in L2 while x streams -- right when the weight image is larger than an XCD's 4 MB L2 (k7, big C).
+    // When the whole packed weight fits L2 comfortably (k = 1 convs), put the R row tiles of a column tile back to back
+    // on one XCD instead: x is then read from HBM once instead of R times.
+    a.row_fast = 0;
+    if (R > 1 && (size_t)a.Cin * KS * a.Mpad * sizeof(float) <= ((size_t)5 << 19)) {          // <= 2.5 MB
+        a.row_fast = (int)R;
+        grid = dim3(((gx + 7) / 8) * 8 * R, 1);
+    }
     hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), lds, stream, a);
     return hipGetLastError();
 }
