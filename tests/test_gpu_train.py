@@ -227,3 +227,52 @@ def test_dropout_train_mode(dev):
     assert torch.allclose(y[keep], x.detach()[keep] / 0.9)
     y.sum().backward()
     assert torch.allclose(x.grad[keep], torch.full_like(x.grad[keep], 1 / 0.9)) and float(x.grad[~keep].abs().sum()) == 0.0
+
+
+@torch.enable_grad()
+def test_reference_step_under_autocast_and_gradscaler(dev):
+    """The reference's step() verbatim (Training/compare_dacvsproposal_5.py:379-397): autocast + GradScaler around
+    forward/backward, net.train() (dropout on), separate loss modules, clip, scaler.step, EMA.  The path computes in fp32
+    regardless; the scaled loss must give the same (unscaled) update as the plain fp32 step."""
+    from multimodal_vqvae_compression_audio_tactile_amd import (AllPredAR, MelCosineLoss, MultiResSTFTLoss, build_proposed,
+                                                                safe_l1, synth)
+    sd = synth.proposed_model_state(31, rvq_books=2, rvq_embed=128)
+    T = 320 * 20
+    a = synth.audio_segments(2, seed=3, T=T).to(dev); tc = synth.tactile_segments(2, seed=3, T=T).to(dev)
+    MRSTFT, MELCOS = MultiResSTFTLoss().to(dev), MelCosineLoss().to(dev)
+
+    def run(use_amp):
+        net = build_proposed(sd, rvq_books=2, rvq_embed=128, device=dev, cls=AllPredAR)
+        net.train()
+        net.predict.drop.p = 0.0                       # compare the two runs exactly; dropout itself is tested below
+        params = [p for n, p in net.named_parameters() if p.requires_grad and not n.startswith("vq.books")]
+        opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=1e-5)
+        scaler = torch.amp.GradScaler("cuda", enabled=use_amp)
+        with torch.amp.autocast("cuda", enabled=use_amp):
+            out = net.forward_step(a, tc)
+            y, tgt = out["y_hat"], out["tgt"]
+            total = 0.55 * safe_l1(y, tgt) + 0.25 * MRSTFT(y, tgt) + 0.20 * MELCOS(y, tgt)
+        assert torch.isfinite(total) and total.dtype == torch.float32
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(total).backward()
+        if use_amp:
+            scaler.unscale_(opt)
+        gn = torch.nn.utils.clip_grad_norm_(params, 3.0)
+        scaler.step(opt); scaler.update()
+        net.vq.ema_step(out["r_tokens"])
+        return float(total), float(gn), [p.detach().clone() for p in params]
+
+    l0, g0, p0 = run(False)
+    l1, g1, p1 = run(True)
+    assert l0 == l1
+    assert abs(g0 - g1) <= 1e-4 * g0
+    for x, y in zip(p0, p1):
+        assert torch.allclose(x, y, rtol=0, atol=2e-6)
+    # dropout on: still finite, and different from the dropout-free loss
+    net = build_proposed(sd, rvq_books=2, rvq_embed=128, device=dev, cls=AllPredAR)
+    net.train()
+    torch.manual_seed(0)
+    out = net.forward_step(a, tc)
+    tot = safe_l1(out["y_hat"], out["tgt"])
+    tot.backward()
+    assert torch.isfinite(tot) and all(torch.isfinite(p.grad).all() for n, p in net.named_parameters() if p.grad is not None)
