@@ -163,16 +163,16 @@ def _evaluate(y, tgt, w_l1, w_stft, w_mel, ffts=(256, 512, 1024), hops=(64, 128,
     res = [(n, h) for n, h in zip(ffts, hops) if T >= max(8, n // 2)] if w_stft else []
     spectra = {}
     if w_stft:
-        if not res:                                   # reference fallback for very short clips: 0.1 * l1 (...:171)
-            raise ops.MvqError("MultiResSTFTLoss: clip shorter than every resolution (reference falls back to 0.1*L1); "
-                               "not supported on this path")
+        if not res:                                   # clip shorter than every resolution: 0.1 * l1 (Training/...5.py:171)
+            parts["stft"] = 0.1 * ops.l1_loss_sum(x, t, dy, 0.1 * w_stft / float(B * T)) / float(B * T)
         sc_sum, mag_sum = 0.0, 0.0
         for n, h in res:
             sp = spectra[(n, h)] = _Spectra(x, t, n, h, eps)
             sc, mag, ca, cb = _mrstft_terms(sp, eps)
             sc_sum, mag_sum = sc_sum + sc, mag_sum + mag
             sp.coefs = (ca * (0.5 * w_stft / len(res)), cb * 0.5 * w_stft / len(res))
-        parts["stft"] = 0.5 * sc_sum / len(res) + 0.5 * mag_sum / len(res)
+        if res:
+            parts["stft"] = 0.5 * sc_sum / len(res) + 0.5 * mag_sum / len(res)
     extra = None
     if w_mel:
         key = (MEL_NFFT, MEL_HOP)
