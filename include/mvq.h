@@ -142,6 +142,12 @@ int mvq_rvq_ema_step_f32(const float* z_tokens, float* books, void* scratch,
 int mvq_dac_rvq_f32(const float* z, const float* in_w, const float* in_b, const float* codebook,
                     const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
                     int batch, int c, int t, int nq_use, int k, int dc, void* stream);
+/* The same with upstream's TRAIN-mode quantiser dropout (dac ResidualVectorQuantize.forward under `net.train()`,
+ * Training/compare_dacvsproposal_5.py:401): every stage runs, item b's zq sums only stages < nq_item[b]
+ * (nq_item[batch] int32 on the device, NULL = no dropout); codes / latents of all nq_use stages are produced. */
+int mvq_dac_rvq_items_f32(const float* z, const float* in_w, const float* in_b, const float* codebook,
+                          const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
+                          const int32_t* nq_item, int batch, int c, int t, int nq_use, int k, int dc, void* stream);
 
 /* ---- predictor / glue primitives (CrossPredictor, TokenNorm, PosEnc1D) --------------------------- */
 

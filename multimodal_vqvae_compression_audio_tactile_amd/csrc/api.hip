@@ -297,6 +297,13 @@ int mvq_dac_rvq_f32(const float* z, const float* in_w, const float* in_b, const 
                     const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
                     int batch, int c, int t, int nq_use, int k, int dc, void* stream)
 {
+    return mvq_dac_rvq_items_f32(z, in_w, in_b, codebook, out_w, out_b, zq, codes, latents, nullptr, batch, c, t, nq_use, k, dc, stream);
+}
+
+int mvq_dac_rvq_items_f32(const float* z, const float* in_w, const float* in_b, const float* codebook,
+                          const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
+                          const int32_t* nq_item, int batch, int c, int t, int nq_use, int k, int dc, void* stream)
+{
     if (batch < 0 || t < 0 || (c != 1024 && c != 512 && c != 256) || dc != 8 || (k * dc) % 4 != 0 || nq_use <= 0 || k <= 0 || dc <= 0 || dc > 16)
         return fail(MVQ_EINVAL, "dac_rvq: bad shape B=%d C=%d T=%d nq=%d K=%d Dc=%d (C in {256,512,1024}, Dc = 8)", batch, c, t, nq_use, k, dc);
     if (batch == 0 || t == 0) return MVQ_OK;
@@ -304,7 +311,7 @@ int mvq_dac_rvq_f32(const float* z, const float* in_w, const float* in_b, const 
         return fail(MVQ_EINVAL, "dac_rvq: null tensor");
     const size_t lds = ((size_t)k * dc + k + (size_t)dc * c + 16 * (size_t)dc * 16 + 2 * (size_t)dc * 16 + 2 * 16 * 16) * sizeof(float);
     if (lds > 160 * 1024) return fail(MVQ_EUNSUPPORTED, "dac_rvq: K*Dc too large for LDS (%zu bytes)", lds);
-    hipError_t e = mvq::launch_dac_rvq(z, in_w, in_b, codebook, out_w, out_b, zq, codes, latents, batch, c, t, nq_use, k, dc, S(stream));
+    hipError_t e = mvq::launch_dac_rvq(z, in_w, in_b, codebook, out_w, out_b, zq, codes, latents, nq_item, batch, c, t, nq_use, k, dc, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "dac_rvq");
 }
 

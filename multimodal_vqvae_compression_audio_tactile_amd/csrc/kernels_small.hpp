@@ -66,6 +66,6 @@ hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_o
 hipError_t launch_ema_update(const float* z, const int32_t* idx, float* books, int B, int D, int T, int nb, int K,
                              float decay, hipStream_t s);
 hipError_t launch_dac_rvq(const float* z, const float* in_w, const float* in_b, const float* cb, const float* out_w,
-                          const float* out_b, float* zq, int32_t* codes, float* latents,
+                          const float* out_b, float* zq, int32_t* codes, float* latents, const int32_t* nq_item,
                           int B, int C, int T, int nq, int K, int Dc, hipStream_t s);
 }  // namespace mvq

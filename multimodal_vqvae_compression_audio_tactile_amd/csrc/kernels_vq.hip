@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
     const float* __restrict__ z, const float* __restrict__ in_w, const float* __restrict__ in_b,
     const float* __restrict__ cb, const float* __restrict__ out_w, const float* __restrict__ out_b,
     float* __restrict__ zq, int32_t* __restrict__ codes, float* __restrict__ latents,
-    int B, int T, int nq, int K)
+    const int32_t* __restrict__ nq_item, int B, int T, int nq, int K)
 {
     constexpr int C = 16 * CPT;
     constexpr int Dc = DC;
@@ -285,6 +285,9 @@ __global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
     const bool live = n < N;
     const int bb = live ? n / T : 0, tt = live ? n - bb * T : 0;
     const int c0 = grp * CPT;
+    // train-mode quantiser dropout: item bb sums only its first nq_item[bb] stages (every stage still runs: the residual,
+    // codes and latents of later stages are produced exactly as upstream does under its mask)
+    const int lim = (nq_item && live) ? nq_item[bb] : nq;
 
     float res[CPT], acc[CPT];
 #pragma unroll
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
 #pragma unroll
                 for (int d = 0; d < Dc; ++d) a = dfma(wr[d], pv[d], a);
                 const float zqi = a + ob[j];
-                acc[j] = acc[j] + zqi;
+                if (st < lim) acc[j] = acc[j] + zqi;
                 res[j] = res[j] - zqi;
             }
         }
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
 template <int CPT, int DC>
 static hipError_t launch_dac_rvq_t(const float* z, const float* in_w, const float* in_b, const float* cb,
                                    const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
-                                   int B, int T, int nq, int K, hipStream_t s)
+                                   const int32_t* nq_item, int B, int T, int nq, int K, hipStream_t s)
 {
     constexpr int C = 16 * CPT;
     const int N = B * T;
@@ -406,20 +409,20 @@ static hipError_t launch_dac_rvq_t(const float* z, const float* in_w, const floa
         attr = true;
     }
     hipLaunchKernelGGL(kern, dim3((N + DQ_TOK - 1) / DQ_TOK), dim3(256), lds, s,
-                       z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, B, T, nq, K);
+                       z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K);
     return hipGetLastError();
 }
 
 hipError_t launch_dac_rvq(const float* z, const float* in_w, const float* in_b, const float* cb, const float* out_w,
-                          const float* out_b, float* zq, int32_t* codes, float* latents,
+                          const float* out_b, float* zq, int32_t* codes, float* latents, const int32_t* nq_item,
                           int B, int C, int T, int nq, int K, int Dc, hipStream_t s)
 {
     if (B * T == 0) return hipSuccess;
     if (Dc != 8) return hipErrorInvalidValue;
     switch (C) {
-        case 1024: return launch_dac_rvq_t<64, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, B, T, nq, K, s);
-        case 512:  return launch_dac_rvq_t<32, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, B, T, nq, K, s);
-        case 256:  return launch_dac_rvq_t<16, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, B, T, nq, K, s);
+        case 1024: return launch_dac_rvq_t<64, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K, s);
+        case 512:  return launch_dac_rvq_t<32, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K, s);
+        case 256:  return launch_dac_rvq_t<16, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K, s);
     }
     return hipErrorInvalidValue;
 }

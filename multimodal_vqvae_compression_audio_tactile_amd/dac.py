@@ -336,13 +336,17 @@ class VectorQuantize(nn.Module):
 
 
 class ResidualVectorQuantize(nn.Module):
-    """DAC residual VQ (eval semantics): all stages in one fused launch (mvq_dac_rvq_f32)."""
+    """DAC residual VQ: all stages in one fused launch (mvq_dac_rvq_items_f32).  In ``train()`` mode with
+    ``quantizer_dropout > 0`` upstream draws, for the first int(B*quantizer_dropout) items, a random number of stages in
+    [1, n_codebooks] (torch.randint on the CPU generator, reproduced here call for call) and masks the later stages out of
+    z_q; all stages still run.  Losses are not produced (the reference discards them, `qa, *_ =`)."""
 
     def __init__(self, input_dim: int = 1024, n_codebooks: int = 32, codebook_size: int = 1024,
                  codebook_dim: int = 8, quantizer_dropout: float = 0.0):
         super().__init__()
         self.n_codebooks, self.codebook_size, self.codebook_dim = n_codebooks, codebook_size, codebook_dim
         self.n_q, self.bins = n_codebooks, codebook_size       # probed by get_n_books_and_bins (…5_eval.py:233-246)
+        self.quantizer_dropout = float(quantizer_dropout)
         self.quantizers = nn.ModuleList([VectorQuantize(input_dim, codebook_size, codebook_dim)
                                          for _ in range(n_codebooks)])
         self._stacked = _Packed()
@@ -367,7 +371,17 @@ class ResidualVectorQuantize(nn.Module):
     def forward(self, z, n_quantizers: Optional[int] = None):
         nq = self.n_codebooks if n_quantizers is None else max(1, min(int(n_quantizers), self.n_codebooks))
         in_w, in_b, cb, out_w, out_b = self._weights()
-        zq, codes, latents = ops.dac_rvq(z, in_w, in_b, cb, out_w, out_b, nq)
+        nq_item = None
+        if self.training:                                        # upstream ignores n_quantizers here and runs every stage
+            nq = self.n_codebooks
+            B = z.shape[0]
+            lim = torch.ones((B,)) * self.n_codebooks + 1
+            dropout = torch.randint(1, self.n_codebooks + 1, (B,))
+            n_dropout = int(B * self.quantizer_dropout)
+            lim[:n_dropout] = dropout[:n_dropout]
+            if n_dropout > 0:
+                nq_item = lim.to(torch.int32).to(z.device)
+        zq, codes, latents = ops.dac_rvq(z, in_w, in_b, cb, out_w, out_b, nq, nq_item=nq_item)
         zero = torch.zeros((), device=zq.device)
         return zq, codes, latents, zero, zero.clone()
 
@@ -376,14 +390,15 @@ class DAC(nn.Module):
     """encoder / quantizer / decoder with the 24 kHz hyper-parameters; ``encode`` / ``decode`` as upstream."""
 
     def __init__(self, encoder_dim=64, encoder_rates=ENC_RATES, latent_dim=None, decoder_dim=1536,
-                 decoder_rates=DEC_RATES, n_codebooks=32, codebook_size=1024, codebook_dim=8, sample_rate=24000):
+                 decoder_rates=DEC_RATES, n_codebooks=32, codebook_size=1024, codebook_dim=8, quantizer_dropout=0.0,
+                 sample_rate=24000):
         super().__init__()
         if latent_dim is None:
             latent_dim = encoder_dim * (2 ** len(encoder_rates))
         self.sample_rate = sample_rate
         self.hop_length = int(math.prod(encoder_rates))
         self.encoder = Encoder(encoder_dim, encoder_rates, latent_dim)
-        self.quantizer = ResidualVectorQuantize(latent_dim, n_codebooks, codebook_size, codebook_dim)
+        self.quantizer = ResidualVectorQuantize(latent_dim, n_codebooks, codebook_size, codebook_dim, float(quantizer_dropout))
         self.decoder = Decoder(latent_dim, decoder_dim, decoder_rates)
 
     @classmethod

@@ -175,17 +175,20 @@ def rvq_ema_step_(z_tokens, books, decay=0.99):
     return books
 
 
-def dac_rvq(z, in_w, in_b, codebook, out_w, out_b, n_q):
-    """DAC ResidualVectorQuantize (eval) -> (z_q, codes int64 [B,nq,T], latents [B,nq*Dc,T])."""
+def dac_rvq(z, in_w, in_b, codebook, out_w, out_b, n_q, nq_item=None):
+    """DAC ResidualVectorQuantize -> (z_q, codes int64 [B,nq,T], latents [B,nq*Dc,T]).  ``nq_item`` (int32 [B] on the
+    device): train-mode quantiser dropout -- item b's z_q sums only its first nq_item[b] stages."""
     z = _dev(z, "z")
     B, C, T = z.shape
     _, K, Dc = codebook.shape
     zq = torch.empty_like(z)
     codes = torch.empty(B, n_q, T, device=z.device, dtype=torch.int32)
     lat = torch.empty(B, n_q * Dc, T, device=z.device, dtype=torch.float32)
-    check(_lib.lib().mvq_dac_rvq_f32(z.data_ptr(), in_w.data_ptr(), in_b.data_ptr(), codebook.data_ptr(),
-                                     out_w.data_ptr(), out_b.data_ptr(), zq.data_ptr(), codes.data_ptr(),
-                                     lat.data_ptr(), B, C, T, n_q, K, Dc, _stream()), "mvq_dac_rvq_f32")
+    if nq_item is not None and (nq_item.dtype != torch.int32 or nq_item.numel() != B or not nq_item.is_cuda):
+        raise MvqError("dac_rvq: nq_item must be an int32 HIP tensor with one entry per batch item")
+    check(_lib.lib().mvq_dac_rvq_items_f32(z.data_ptr(), in_w.data_ptr(), in_b.data_ptr(), codebook.data_ptr(),
+                                           out_w.data_ptr(), out_b.data_ptr(), zq.data_ptr(), codes.data_ptr(),
+                                           lat.data_ptr(), _p(nq_item), B, C, T, n_q, K, Dc, _stream()), "mvq_dac_rvq_f32")
     return zq, codes.long(), lat
 
 
