@@ -1,6 +1,8 @@
 // conv_tr.hip -- DecoderBlock ConvTranspose1d (kernel 2*s, stride s) in polyphase form: a 2-tap conv
 // over Cout*s GEMM rows with a pixel-shuffle store.
 #include "conv_dispatch.hpp"
+// 16 channels x 2 taps per LDS stage: 49 KB of staging per block (two to three blocks per CU).  With 32-channel stages
+// (98 KB, one block per CU) these layers ran at 77-101 TFLOP/s instead of 97-118.
 namespace mvq {
 hipError_t launch_conv_tr(const ConvArgs& a, int bm, hipStream_t s)
 {
@@ -14,13 +16,13 @@ hipError_t launch_conv_tr(const ConvArgs& a, int bm, hipStream_t s)
     }
     const bool narrow = bm == 128 && a.Ncols <= 96;
     switch (a.up_s) {
-        case 8: if (bm == 128) return narrow ? launch_conv1d_mfma<2, 1, 1, 32, 1, 3, 4, 1, 8>(a, s)
-                                              : launch_conv1d_mfma<2, 1, 1, 32, 2, 2, 2, 2, 8>(a, s);
+        case 8: if (bm == 128) return narrow ? launch_conv1d_mfma<2, 1, 1, 16, 1, 3, 4, 1, 8>(a, s)
+                                              : launch_conv1d_mfma<2, 1, 1, 16, 2, 2, 2, 2, 8>(a, s);
                 break;
-        case 5: if (bm == 128) return launch_conv1d_mfma<2, 1, 1, 32, 2, 2, 2, 2, 5>(a, s); break;
-        case 4: if (bm == 128) return launch_conv1d_mfma<2, 1, 1, 32, 2, 2, 2, 2, 4>(a, s); break;
-        case 2: if (bm == 96) return launch_conv1d_mfma<2, 1, 1, 32, 3, 1, 1, 4, 2>(a, s);
-                if (bm == 128) return launch_conv1d_mfma<2, 1, 1, 32, 2, 2, 2, 2, 2>(a, s);
+        case 5: if (bm == 128) return launch_conv1d_mfma<2, 1, 1, 16, 2, 2, 2, 2, 5>(a, s); break;
+        case 4: if (bm == 128) return launch_conv1d_mfma<2, 1, 1, 16, 2, 2, 2, 2, 4>(a, s); break;
+        case 2: if (bm == 96) return launch_conv1d_mfma<2, 1, 1, 16, 3, 1, 1, 4, 2>(a, s);
+                if (bm == 128) return launch_conv1d_mfma<2, 1, 1, 16, 2, 2, 2, 2, 2>(a, s);
                 break;
     }
     return hipErrorInvalidValue;

@@ -40,7 +40,7 @@ def test_host_only_entry_points():
     assert ops.conv_kernel_name(768, 768, 7, 1, 9, tin=600).startswith("conv1d_mfma_kernel<7, 1, 9, 8, 2, 2, 2, 2")
     assert ops.conv_kernel_name(768, 768, 7, 1, 9, tin=600, batch=1).startswith("conv1d_mfma_kernel<7, 1, 9, 8, 1, 1, 2, 2")
     assert ops.conv_kernel_name(1024, 1536, 7, tin=75, batch=64) == "conv1d_mfma_kernel<7, 1, 1, 8, 1, 3, 4, 1, 0>"
-    assert ops.conv_kernel_name(1536, 768, 16, 8, 1, True, tin=75) == "conv1d_mfma_kernel<2, 1, 1, 32, 1, 3, 4, 1, 8>"
+    assert ops.conv_kernel_name(1536, 768, 16, 8, 1, True, tin=75) == "conv1d_mfma_kernel<2, 1, 1, 16, 1, 3, 4, 1, 8>"
     assert ops.conv_kernel_name(1, 64, 7) == "conv1d_cin1_kernel<7>" and ops.conv_kernel_name(40, 24, 5, 2, 2) == "conv1d_direct_kernel"
     assert ops.residual_unit_kernel_name(96, 3) == "residual_unit_kernel<3, 8, 3, 1, 1, 4>"
     assert ops.conv1d_out_len(24000, 4, 2, 1, 1) == 12000 and ops.conv1d_out_len(600, 16, 8, 1, 4) == 75
