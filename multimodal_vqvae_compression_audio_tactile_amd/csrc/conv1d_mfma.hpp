@@ -77,7 +77,18 @@ struct ConvCfg {
     static constexpr int STAGE_FLOATS = 2 * (W_FLOATS + X_FLOATS);
     static constexpr int BNP = BN + 4;                                   // pitch of the epilogue tile
     static constexpr int CT_FLOATS = BM * BNP;
-    static constexpr int LDS_FLOATS = STAGE_FLOATS > CT_FLOATS ? STAGE_FLOATS : CT_FLOATS;
+    // plain convs with an even number of row groups per wave drain the accumulators in two passes (half the rows each)
+    // when that is what keeps the block's LDS footprint down (more co-resident blocks per CU)
+    static constexpr int EH = (UPS == 0 && MT % 2 == 0 && CT_FLOATS > STAGE_FLOATS) ? 2 : 1;
+    static constexpr int CTH_FLOATS = CT_FLOATS / EH;
+    static constexpr int LDS_FLOATS = STAGE_FLOATS > CTH_FLOATS ? STAGE_FLOATS : CTH_FLOATS;
+#ifdef MVQ_WPE3
+    // waves per SIMD the register allocator is asked to leave room for: 3 where the LDS footprint allows 3 blocks per CU
+    static constexpr int MIN_WPE = (WAVES_M * WAVES_N == 4 && LDS_FLOATS * 4 <= 53 * 1024 && !(WAVES_N == 4 && NT == 2)) ? 3 : (WAVES_M * WAVES_N) / 2;
+#else
+    static constexpr int MIN_WPE = (WAVES_M * WAVES_N) / 2;
+#endif
+    static constexpr int LDS_FLOATS_FUSE = STAGE_FLOATS > CT_FLOATS ? STAGE_FLOATS : CT_FLOATS;   // fused unit: full tile
     static constexpr int W_VEC = W_FLOATS / 4;                           // float4 per chunk
     static constexpr int NTHR = 64 * WAVES_M * WAVES_N;                  // threads per block
     static constexpr int W_PER_THREAD = (W_VEC + NTHR - 1) / NTHR;
@@ -196,7 +207,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ws = smem;                          // [2][KC][BM]
     float* const Xs = smem + 2 * C::W_FLOATS;        // [2][CK][XTP]
-    float* const Al = smem + C::LDS_FLOATS;          // [2][Cin]: alpha, 1/(alpha+1e-9)   (only with alpha_in)
+    float* const Al = smem + (FUSE ? C::LDS_FLOATS_FUSE : C::LDS_FLOATS);   // [2][Cin]: alpha, 1/(alpha+1e-9) (only with alpha_in)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -420,26 +431,37 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         return;
     }
 
-    float* const Ct = smem;                          // [BM][BNP]
-    __syncthreads();                                  // every wave is done with the staging buffers
+    float* const Ct = smem;                          // [BM / EHP][BNP]
+    constexpr int EHP = FUSE ? 1 : C::EH;            // epilogue passes
+    constexpr int MTH = MT / EHP;                    // row groups per wave per pass
+    constexpr int BMH = C::BM / EHP;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int hp = 0; hp < EHP; ++hp) {
+    __syncthreads();                                  // every wave is done with the staging buffers / the previous pass
+#pragma unroll
+    for (int il = 0; il < MTH; ++il)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int row = (wm * MTH + il) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) Ct[row * C::BNP + (wn * NT + j) * 32 + l31] = acc[i][j][r];
+            for (int j = 0; j < NT; ++j) Ct[row * C::BNP + (wn * NT + j) * 32 + l31] = acc[hp * MTH + il][j][r];
         }
     __syncthreads();
+    // local row -> row of the block tile: group g = lrow / 32 belongs to wave row g / MTH, its (hp*MTH + g % MTH)-th group
+    auto tile_row = [&](int lrow) __attribute__((always_inline)) {
+        if (EHP == 1) return lrow;
+        const int g = lrow >> 5;
+        return ((g / MTH) * MT + hp * MTH + (g % MTH)) * 32 + (lrow & 31);
+    };
 
     if (UPS == 0) {
         if (a.ovec4) {
-            constexpr int NV = C::BM * C::BN / 4;
+            constexpr int NV = BMH * C::BN / 4;
 #pragma unroll 4
             for (int e = tid; e < NV; e += C::NTHR) {
                 const int row = e / (C::BN / 4);
                 const int c4 = e - row * (C::BN / 4);
-                const int m = m0 + row, n = n0 + 4 * c4;
+                const int m = m0 + tile_row(row), n = n0 + 4 * c4;
                 if (m < a.Mrows && n < a.Ncols) {
                     const float bv = ep_bias ? ep_bias[m] : 0.0f;
                     f32x4 v = *reinterpret_cast<const f32x4*>(Ct + row * C::BNP + 4 * c4);
@@ -470,12 +492,12 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 }
             }
         } else {
-            constexpr int NE = C::BM * C::BN;
+            constexpr int NE = BMH * C::BN;
 #pragma unroll 4
             for (int e = tid; e < NE; e += C::NTHR) {
                 const int row = e / C::BN;
                 const int col = e - row * C::BN;
-                const int m = m0 + row, n = n0 + col;
+                const int m = m0 + tile_row(row), n = n0 + col;
                 if (m < a.Mrows && n < a.Ncols) {
                     const size_t off = ((size_t)b * a.Cout + m) * a.Tout + n;
                     float v = Ct[row * C::BNP + col] + (ep_bias ? ep_bias[m] : 0.0f);
@@ -510,12 +532,15 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             }
         }
     }
+    }   // epilogue pass
 }
 
 // 16-byte input rows (Tin % 4 == 0) take the float4 staging path; the two paths are separate loop nests so that
 // no control-flow merge sits between a chunk's global loads and the MFMAs that hide them.
 template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, int UPS>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 2) void conv1d_mfma_kernel(const ConvArgs a)
+__global__ __attribute__((amdgpu_flat_work_group_size(1, 64 * WAVES_M * WAVES_N),
+                          amdgpu_waves_per_eu(ConvCfg<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS>::MIN_WPE)))
+void conv1d_mfma_kernel(const ConvArgs a)
 {
     if (a.vec4) conv1d_mfma_body<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS, true, false>(a);
     else conv1d_mfma_body<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS, false, false>(a);
@@ -543,7 +568,7 @@ inline hipError_t launch_residual_unit(const ConvArgs& a_in, hipStream_t stream)
     a.vec4 = (a.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     a.ovec4 = (a.Tout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
               ((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0);
-    const size_t lds = (size_t)C::LDS_FLOATS * 4 + (size_t)2 * a.Cin * 4;
+    const size_t lds = (size_t)C::LDS_FLOATS_FUSE * 4 + (size_t)2 * a.Cin * 4;
     auto kern = residual_unit_kernel<DIL, CK, MT, NT, WAVES_M, WAVES_N>;
     static bool attr_set = false;
     if (!attr_set) {
