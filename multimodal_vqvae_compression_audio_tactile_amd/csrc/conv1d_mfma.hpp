@@ -79,7 +79,7 @@ struct ConvCfg {
     static constexpr int CT_FLOATS = BM * BNP;
     // plain convs with an even number of row groups per wave drain the accumulators in two passes (half the rows each)
     // when that is what keeps the block's LDS footprint down (more co-resident blocks per CU)
-    static constexpr int EH = (UPS == 0 && MT % 2 == 0 && CT_FLOATS > STAGE_FLOATS) ? 2 : 1;
+    static constexpr int EH = ((UPS == 0 || 32 % (UPS ? UPS : 1) == 0) && MT % 2 == 0 && CT_FLOATS > STAGE_FLOATS) ? 2 : 1;
     static constexpr int CTH_FLOATS = CT_FLOATS / EH;
     static constexpr int LDS_FLOATS = STAGE_FLOATS > CTH_FLOATS ? STAGE_FLOATS : CTH_FLOATS;
 #ifdef MVQ_WPE3
@@ -512,16 +512,17 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         }
     } else {
         // pixel shuffle: for each output channel of this tile the S phases interleave into one contiguous run
+        // (a pass holds whole 32-row groups, i.e. 32/S whole channels each, so the two-pass form applies unchanged)
         constexpr int S = UPS ? UPS : 1;
         const int run = C::BN * S;                    // output samples per channel covered by this tile
-        const int nco = C::BM / S;
+        const int nco = BMH / S;
         const int t_base = n0 * S - a.up_p;
         const int total = nco * run;
         for (int e = tid; e < total; e += C::NTHR) {
             const int col = e / run;
             const int tl = e - col * run;
             const int nl = tl / S, rr = tl - nl * S;
-            const int co = m0 / S + col;
+            const int co = (m0 + tile_row(col * S)) / S;
             const int t = t_base + tl;
             if (co < a.Cout && n0 + nl < a.Ncols && t >= 0 && t < a.Tout) {
                 float v = Ct[(col * S + rr) * C::BNP + nl] + (ep_bias ? ep_bias[co] : 0.0f);

@@ -6,13 +6,13 @@ hipError_t launch_conv_k1k3(const ConvArgs& a, int ks, int bm, hipStream_t s)
     if (ks == 1) {
         if (bm != 96 && conv_prefer_small_tiles(a)) return launch_conv1d_mfma<1, 1, 1, 32, 1, 1, 2, 2, 0>(a, s);
         switch (bm) {
-            case 128: return launch_conv1d_mfma<1, 1, 1, 32, 2, 2, 2, 2, 0>(a, s);
+            case 128: return launch_conv1d_mfma<1, 1, 1, 16, 2, 2, 2, 2, 0>(a, s);
             case 96:  return launch_conv1d_mfma<1, 1, 1, 16, 3, 1, 1, 4, 0>(a, s);   // 142 VGPRs -> 3 waves/SIMD: +11 % on the C = 192 layer
             case 64:  return launch_conv1d_mfma<1, 1, 1, 32, 2, 2, 1, 4, 0>(a, s);
         }
     } else if (ks == 3) {
         if (bm != 96 && conv_prefer_small_tiles(a)) return launch_conv1d_mfma<3, 1, 1, 16, 1, 1, 2, 2, 0>(a, s);
-        if (bm == 128 && a.Ncols <= 96) return launch_conv1d_mfma<3, 1, 1, 16, 1, 3, 4, 1, 0>(a, s);
+        if (bm == 128 && a.Ncols <= 96) return launch_conv1d_mfma<3, 1, 1, 8, 1, 3, 4, 1, 0>(a, s);
         switch (bm) {
             case 128: return launch_conv1d_mfma<3, 1, 1, 16, 2, 2, 2, 2, 0>(a, s);
         }

@@ -11,11 +11,11 @@ template <int DIL>
 static hipError_t k7(const ConvArgs& a, int bm, hipStream_t s)
 {
     if (DIL == 1 && bm == 128 && a.Ncols <= 96 && !conv_prefer_small_tiles(a))          // latent-rate layer (T = 75): 128 x 96 tile instead of 128 x 128
-        return launch_conv1d_mfma<7, 1, 1, 8, 1, 3, 4, 1, 0>(a, s);
+        return launch_conv1d_mfma<7, 1, 1, 4, 1, 3, 4, 1, 0>(a, s);
     if (bm != 96 && conv_prefer_small_tiles(a)) return launch_conv1d_mfma<7, 1, DIL, 8, 1, 1, 2, 2, 0>(a, s);
     switch (bm) {
         case 128: return launch_conv1d_mfma<7, 1, DIL, MVQ_K7_CK, MVQ_K7_TILE, 0>(a, s);
-        case 96:  return launch_conv1d_mfma<7, 1, DIL, 8, 3, 1, 1, 4, 0>(a, s);
+        case 96:  return launch_conv1d_mfma<7, 1, DIL, 4, 3, 1, 1, 4, 0>(a, s);
         case 64:  return launch_conv1d_mfma<7, 1, DIL, 8, 2, 2, 1, 4, 0>(a, s);
     }
     return hipErrorInvalidValue;

@@ -19,7 +19,7 @@ hipError_t launch_conv_strided(const ConvArgs& a, int stride, int bm, hipStream_
     switch (stride) {
         case 2: return launch_conv1d_mfma<4, 2, 1, 8, 2, 2, 2, 2, 0>(a, s);
         case 4: return launch_conv1d_mfma<8, 4, 1, 4, 2, 2, 2, 2, 0>(a, s);
-        case 5: return launch_conv1d_mfma<10, 5, 1, 4, 2, 2, 2, 2, 0>(a, s);
+        case 5: return launch_conv1d_mfma<10, 5, 1, 2, 2, 2, 2, 2, 0>(a, s);
         case 8: return a.Ncols <= 96 ? launch_conv1d_mfma<16, 8, 1, 2, 1, 3, 4, 1, 0>(a, s)
                                      : launch_conv1d_mfma<16, 8, 1, 2, 2, 2, 2, 2, 0>(a, s);
     }
