@@ -89,6 +89,11 @@ struct ConvCfg {
     static constexpr int MIN_WPE = (WAVES_M * WAVES_N) / 2;
 #endif
     static constexpr int LDS_FLOATS_FUSE = STAGE_FLOATS > CT_FLOATS ? STAGE_FLOATS : CT_FLOATS;   // fused unit: full tile
+#ifdef MVQ_WPE3
+    static constexpr int MIN_WPE_FUSE = (WAVES_M * WAVES_N == 4 && (LDS_FLOATS_FUSE + 2 * BM) * 4 <= 53 * 1024) ? 3 : (WAVES_M * WAVES_N) / 2;
+#else
+    static constexpr int MIN_WPE_FUSE = (WAVES_M * WAVES_N) / 2;
+#endif
     static constexpr int W_VEC = W_FLOATS / 4;                           // float4 per chunk
     static constexpr int NTHR = 64 * WAVES_M * WAVES_N;                  // threads per block
     static constexpr int W_PER_THREAD = (W_VEC + NTHR - 1) / NTHR;
@@ -549,7 +554,9 @@ void conv1d_mfma_kernel(const ConvArgs a)
 
 // whole ResidualUnit (7-tap dilated conv + Snake + 1x1 conv + skip) for C == BM
 template <int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 2) void residual_unit_kernel(const ConvArgs a)
+__global__ __attribute__((amdgpu_flat_work_group_size(1, 64 * WAVES_M * WAVES_N),
+                          amdgpu_waves_per_eu(ConvCfg<7, 1, DIL, CK, MT, NT, WAVES_M, WAVES_N, 0>::MIN_WPE_FUSE)))
+void residual_unit_kernel(const ConvArgs a)
 {
     if (a.vec4) conv1d_mfma_body<7, 1, DIL, CK, MT, NT, WAVES_M, WAVES_N, 0, true, true>(a);
     else conv1d_mfma_body<7, 1, DIL, CK, MT, NT, WAVES_M, WAVES_N, 0, false, true>(a);

@@ -7,7 +7,7 @@ static hipError_t ru(const ConvArgs& a, int c, hipStream_t s)
 {
     switch (c) {
         case 128: return launch_residual_unit<DIL, 8, 2, 2, 2, 2>(a, s);
-        case 96:  return launch_residual_unit<DIL, 8, 3, 1, 1, 4>(a, s);
+        case 96:  return launch_residual_unit<DIL, 4, 3, 1, 1, 4>(a, s);
         case 64:  return launch_residual_unit<DIL, 8, 2, 2, 1, 4>(a, s);
     }
     return hipErrorInvalidValue;
