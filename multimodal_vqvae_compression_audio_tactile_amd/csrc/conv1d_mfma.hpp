@@ -82,18 +82,15 @@ struct ConvCfg {
     static constexpr int EH = ((UPS == 0 || 32 % (UPS ? UPS : 1) == 0) && MT % 2 == 0 && CT_FLOATS > STAGE_FLOATS) ? 2 : 1;
     static constexpr int CTH_FLOATS = CT_FLOATS / EH;
     static constexpr int LDS_FLOATS = STAGE_FLOATS > CTH_FLOATS ? STAGE_FLOATS : CTH_FLOATS;
-#ifdef MVQ_WPE3
-    // waves per SIMD the register allocator is asked to leave room for: 3 where the LDS footprint allows 3 blocks per CU
-    static constexpr int MIN_WPE = (WAVES_M * WAVES_N == 4 && LDS_FLOATS * 4 <= 53 * 1024 && !(WAVES_N == 4 && NT == 2)) ? 3 : (WAVES_M * WAVES_N) / 2;
-#else
-    static constexpr int MIN_WPE = (WAVES_M * WAVES_N) / 2;
-#endif
+    // Waves per SIMD the register allocator is asked to leave room for (= blocks per CU for a 4-wave block): 3 where the
+    // block's LDS footprint fits three times into 160 KB (the kernels then need 112-165 VGPRs of the 168 allowed, no
+    // spills).  Four (128 VGPRs) was measured on the 7-tap 128x128 tile: 7 dwords of scratch, +1.5 % in isolation, nothing
+    // on the whole step -- not kept.
+    static constexpr bool FOUR_WAVES = WAVES_M * WAVES_N == 4;
+    static constexpr int MIN_WPE = (FOUR_WAVES && LDS_FLOATS * 4 <= 53 * 1024 && !(WAVES_N == 4 && NT == 2)) ? 3
+                                                                                                                : (WAVES_M * WAVES_N) / 2;
     static constexpr int LDS_FLOATS_FUSE = STAGE_FLOATS > CT_FLOATS ? STAGE_FLOATS : CT_FLOATS;   // fused unit: full tile
-#ifdef MVQ_WPE3
-    static constexpr int MIN_WPE_FUSE = (WAVES_M * WAVES_N == 4 && (LDS_FLOATS_FUSE + 2 * BM) * 4 <= 53 * 1024) ? 3 : (WAVES_M * WAVES_N) / 2;
-#else
-    static constexpr int MIN_WPE_FUSE = (WAVES_M * WAVES_N) / 2;
-#endif
+    static constexpr int MIN_WPE_FUSE = (FOUR_WAVES && (LDS_FLOATS_FUSE + 2 * BM) * 4 <= 53 * 1024) ? 3 : (WAVES_M * WAVES_N) / 2;
     static constexpr int W_VEC = W_FLOATS / 4;                           // float4 per chunk
     static constexpr int NTHR = 64 * WAVES_M * WAVES_N;                  // threads per block
     static constexpr int W_PER_THREAD = (W_VEC + NTHR - 1) / NTHR;
