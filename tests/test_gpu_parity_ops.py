@@ -49,6 +49,18 @@ CONV_CASES = [
     (1, 256, 3000, 512, 10, 5, 1, 3, False, False, True, False),
     (1, 128, 1200, 256, 8, 4, 1, 2, False, False, False, False),
     (1, 64, 800, 128, 4, 2, 1, 1, False, False, False, False),
+    # throughput regime (grid >= 160 big tiles): the 128/96-row tiles, two-pass epilogue, XCD-aware row-fast order,
+    # three blocks per CU -- odd lengths take the scalar staging / store paths
+    (6, 256, 3503, 256, 7, 1, 3, 9, False, False, True, False),   # 128x128 k7, unaligned rows, Snake epilogue
+    (5, 256, 3200, 256, 7, 1, 9, 27, True, True, False, False),   # aligned rows, Snake on load, residual
+    (4, 384, 2999, 384, 1, 1, 1, 0, False, True, False, False),   # k1, 3 row tiles in row-fast order, unaligned (dec.b1)
+    (4, 192, 2600, 200, 1, 1, 1, 0, False, True, True, False),    # partial last row tile (200 rows)
+    (4, 192, 6000, 192, 7, 1, 9, 27, False, False, True, False),  # 96-row tile
+    (4, 192, 6001, 192, 1, 1, 1, 0, False, True, False, False),   # 96-row k1, unaligned
+    (4, 128, 12000, 256, 8, 4, 1, 2, False, False, True, False),  # strided s=4, 128-row tile
+    (3, 64, 20000, 128, 4, 2, 1, 1, False, False, False, False),  # strided s=2
+    (4, 256, 9000, 512, 10, 5, 1, 3, False, False, False, False), # strided s=5
+    (8, 1024, 75, 1024, 3, 1, 1, 1, False, False, False, False),  # k3 at the latent rate, 128x96 tile
 ]
 
 
@@ -87,6 +99,11 @@ CONVTR_CASES = [
     (1, 256, 40, 128, 2, True, True),    # stride 2 with a 128-row tile
     (1, 768, 600, 384, 5, False, True),  # latency regime: 64-row tile, 5 phases (direct store)
     (1, 384, 299, 192, 4, True, False),  # latency regime: 64-row tile, pixel-shuffle through LDS
+    # throughput regime: 128/96-row tiles, two-pass pixel-shuffle epilogue
+    (8, 384, 701, 192, 4, False, True),
+    (6, 768, 333, 384, 5, False, False),  # 5 phases: direct store
+    (8, 192, 1500, 96, 2, True, False),   # 96-row tile
+    (24, 1536, 75, 768, 8, False, True),  # latent rate, 128x96 tile
 ]
 
 
@@ -215,7 +232,8 @@ def test_ops_refuse_cpu_tensors():
 
 
 RU_CASES = [(2, 64, 1000, 1, True), (1, 64, 517, 9, False), (2, 96, 700, 3, True), (1, 96, 333, 1, False),
-            (2, 128, 600, 9, True), (1, 128, 257, 3, False), (1, 192, 300, 3, True), (1, 256, 75, 1, False)]
+            (2, 128, 600, 9, True), (1, 128, 257, 3, False), (1, 192, 300, 3, True), (1, 256, 75, 1, False),
+            (3, 96, 11997, 9, True), (3, 128, 6001, 3, True), (4, 64, 9999, 1, False), (3, 96, 8000, 1, False)]
 
 
 @pytest.mark.parametrize("case", RU_CASES, ids=[f"ru{i}" for i in range(len(RU_CASES))])
