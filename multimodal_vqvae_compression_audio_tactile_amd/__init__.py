@@ -17,7 +17,8 @@ from .losses import MelCosineLoss, MultiResSTFTLoss, TrainingLoss, safe_l1, stsi
 from ._lib import MvqError, build, lib  # noqa: F401
 from .dac import DAC, Decoder, Encoder, ResidualVectorQuantize, VectorQuantize, Snake1d, WNConv1d, WNConvTranspose1d  # noqa: F401
 from .proposed import (AllPredAR, CrossPredictor, PosEnc1D, ProposedEval, ResidualVQEMA, TokenNorm,  # noqa: F401
-                       psnr_batch, psnr_global_peak_db, align_by_xcorr, crop_match)
+                       psnr_batch, psnr_global_peak_db, align_by_xcorr, crop_match, align_pair_24k,
+                       psnr_3k_aligned_batch)
 
 
 def build_proposed(state_dict=None, rvq_books=8, rvq_embed=512, n_codebooks=32, device="cuda", cls=None):

@@ -286,6 +286,24 @@ def align_xcorr(ref, est, max_shift=200):
     return corr, best
 
 
+def align_xcorr_batch(ref, est, max_shift=200):
+    """Best shift per item for ref[B,T] / est[B,T] (equal lengths): B launches on the stream, NO host sync; returns the
+    int32 device tensor of shifts (read it once for the whole batch)."""
+    ref = _dev(ref, "ref"); est = _dev(est, "est")
+    if ref.shape != est.shape or ref.dim() != 2:
+        raise MvqError("align_xcorr_batch: ref and est must both be [B, T]")
+    B, T = ref.shape
+    n = 2 * max_shift + 1
+    corr = torch.empty(B, n, device=ref.device, dtype=torch.float32)
+    scratch = torch.empty(B, n, device=ref.device, dtype=torch.int32)
+    best = torch.zeros(B, device=ref.device, dtype=torch.int32)
+    f = _lib.lib().mvq_align_xcorr_f32
+    for b in range(B):
+        check(f(ref.data_ptr() + 4 * b * T, est.data_ptr() + 4 * b * T, T, max_shift, corr.data_ptr() + 4 * b * n,
+                scratch.data_ptr() + 4 * b * n, best.data_ptr() + 4 * b, _stream()), "mvq_align_xcorr_f32")
+    return best
+
+
 # ---------------------------------------------------------------------------------- backward (row f1)
 def pack_conv1d_dgrad(w: torch.Tensor) -> torch.Tensor:
     """Conv1d weight w[Cout,Cin,ks] -> packed image of its input-gradient conv (flip + transpose)."""

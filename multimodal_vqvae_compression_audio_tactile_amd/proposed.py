@@ -361,3 +361,42 @@ def align_by_xcorr(ref_1T, est_1T, max_shift=200):
     else:
         r_a = r; e_a = e[: r.numel()]
     return r_a.unsqueeze(0), e_a.unsqueeze(0), s
+
+
+ALIGN_MAX_SHIFT_SAMPLES = 200      # Evaluation/compare_dacvsproposal_5_eval.py:69
+EVAL_SR, ORIG_3K = 24000, 3000     # ...:52-53
+
+
+@torch.no_grad()
+def align_pair_24k(ref_24, est_24, max_shift=ALIGN_MAX_SHIFT_SAMPLES):
+    """Evaluation/compare_dacvsproposal_5_eval.py:188-210 ([1,1,T] in, [1,1,T'] out)."""
+    r_a, e_a, s = align_by_xcorr(ref_24.reshape(1, -1), est_24.reshape(1, -1), max_shift)
+    return r_a.unsqueeze(0), e_a.unsqueeze(0), s
+
+
+@torch.no_grad()
+def psnr_3k_aligned_batch(ref_24, est_24, max_shift=ALIGN_MAX_SHIFT_SAMPLES):
+    """Evaluation/compare_dacvsproposal_5_eval.py:212-223: per item, align at 24 kHz (+-200 samples), resample both to
+    3 kHz, PSNR with peak 1.  All B alignments are queued without a host sync and their shifts read back ONCE; the
+    PSNR values likewise come back in one copy (the reference syncs 401 + 1 times per item)."""
+    from .resample import Resample
+    ref = ref_24.reshape(ref_24.shape[0], -1).to(torch.float32).contiguous()
+    est = est_24.reshape(est_24.shape[0], -1).to(torch.float32).contiguous()
+    B = ref.shape[0]
+    if B == 0:
+        return []
+    shifts = ops.align_xcorr_batch(ref, est, max_shift).cpu().tolist()
+    down = Resample(EVAL_SR, ORIG_3K).to(ref.device)
+    vals = []
+    for b, s in enumerate(shifts):
+        r, e = ref[b], est[b]
+        if s < 0:
+            r_a = r[-s:]; e_a = e[: r_a.numel()]
+        elif s > 0:
+            r_a = r[:-s]; e_a = e[s: s + r_a.numel()]
+        else:
+            r_a = r; e_a = e[: r.numel()]
+        r3, e3 = down(r_a.reshape(1, -1)), down(e_a.reshape(1, -1))
+        mse = (r3 - e3).pow(2).mean().clamp_min(1e-12)
+        vals.append(10.0 * torch.log10(1.0 / mse))
+    return [float(v) for v in torch.stack(vals).cpu()]

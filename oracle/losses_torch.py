@@ -108,3 +108,16 @@ def stsim_batch(ref_1T, est_1T, fb=None):
     num = (R * E).sum(dim=1)
     den = (R.norm(dim=1) * E.norm(dim=1)).clamp_min(1e-8)
     return [float(v) for v in 0.5 * ((num / den).clamp(-1, 1).mean(dim=-1) + 1.0)]
+
+
+class Resample(torch.nn.Module):
+    """Stand-in for torchaudio.transforms.Resample (absent) inside the reference's own functions when fixtures are
+    generated: the restated sinc-hann resampler of oracle/oracle.py behind the torchaudio call shape."""
+
+    def __init__(self, orig_freq=16000, new_freq=16000, **_):
+        super().__init__()
+        self.orig_freq, self.new_freq = int(orig_freq), int(new_freq)
+
+    def forward(self, x):
+        from . import oracle as _orc
+        return torch.from_numpy(_orc.resample(x.detach().cpu().numpy(), self.orig_freq, self.new_freq))

@@ -18,6 +18,8 @@ patched) and records inputs-by-seed + expected outputs of:
      dropout off; fp32, no autocast).  Stored: the losses, y_hat, dL/dy_hat and for every trainable tensor its norm
      and the subsample flat[::997].
   G8 stsim_batch (Evaluation/compare_dacvsproposal_5_eval.py:142-177), MelScale stand-in as in G7
+  G9 psnr_3k_aligned_batch (Evaluation/compare_dacvsproposal_5_eval.py:188-223): align at 24 kHz, resample to 3 kHz, PSNR;
+     torchaudio's Resample replaced by the restated resampler (oracle), as MelScale is in G7/G8
   G5 psnr_batch / psnr_global_peak_db (Evaluation/compare_dacvsproposal_5_eval.py:180-185, ...6_latency.py:204-214)
 Only data is stored (arrays), never reference source.  Inputs are re-created from seeds by tests/golden_inputs.py.
 """
@@ -151,6 +153,12 @@ def main():
     e5.torchaudio.transforms.MelScale = LT.MelScale
     ref, est = gi.stsim_inputs()
     np.savez_compressed(OUT / "g8_stsim.npz", stsim=np.array(e5.stsim_batch(ref, est), np.float64))
+    # ---- G9: aligned 3 kHz PSNR from the reference functions
+    e5.torchaudio.transforms.Resample = LT.Resample
+    ref, est, lags = gi.aligned_psnr_inputs()
+    shifts = [e5.align_pair_24k(ref[i:i + 1], est[i:i + 1])[2] for i in range(ref.shape[0])]
+    np.savez_compressed(OUT / "g9_aligned_psnr.npz", psnr=np.array(e5.psnr_3k_aligned_batch(ref, est), np.float64),
+                        shifts=np.array(shifts, np.int64))
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size // 1024, "KiB")
 

@@ -28,3 +28,17 @@ def test_resample_identity_and_empty(dev):
     x = torch.randn(1, 100, device=dev)
     assert resample_to(x, 24000, 24000) is x
     assert Resample(3000, 24000).to(dev)(torch.zeros(1, 0, device=dev)).shape == (1, 0)
+
+
+def test_psnr_3k_aligned_batch_matches_reference_fixture(dev):
+    """G9: the reference's align_pair_24k + resample + psnr_batch chain (fixture from the reference functions)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import golden_inputs as gi
+    from multimodal_vqvae_compression_audio_tactile_amd import align_pair_24k, psnr_3k_aligned_batch
+    G9 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_aligned_psnr.npz"))
+    ref, est, lags = gi.aligned_psnr_inputs()
+    got = psnr_3k_aligned_batch(ref.to(dev), est.to(dev))
+    assert np.allclose(got, G9["psnr"], rtol=0, atol=2e-4), (got, G9["psnr"])
+    for i in range(ref.shape[0]):
+        assert align_pair_24k(ref[i:i + 1].to(dev), est[i:i + 1].to(dev))[2] == int(G9["shifts"][i]) == lags[i]

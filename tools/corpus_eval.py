@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[3]: the reference's corpus evaluation loop
+(Evaluation/compare_dacvsproposal_5_eval.py:396-470) on the drop-in modules, over a SYNTHETIC corpus (the real
+Vibrotactile_Files corpus and the checkpoints are not available offline): 1 003 clips (the published n), length uniform
+in [1 s, 4 s] rounded to 320 samples, tactile generated at 3 kHz and audio at 44.1 kHz and resampled to 24 kHz on the
+device (row f3), cut into 1-s segments (last one reflect-padded, ...5.py:115-124), segment i -> rank i mod world,
+batches of --batch segments through ProposedEval.forward_eval, then the reference's metrics per segment -- ST-SIM
+(stsim_batch) and the aligned 3 kHz PSNR (psnr_3k_aligned_batch) -- aggregated to mean +- CI95 exactly as the reference
+does.  The only collective is the final gather of the per-rank metric lists.
+
+  python tools/corpus_eval.py [--clips 1003] [--batch 64]
+  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/corpus_eval.py --gpus N
+"""
+import argparse, json, math, os, sys, time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+SEG = 24000
+PCM_KBPS_TACT_ORIG = 3000 * 16.0 / 1000.0          # Evaluation/compare_dacvsproposal_5_eval.py:66
+
+
+def reflect_pad_right(x, need):                     # Training/compare_dacvsproposal_5.py:115-124
+    while need > 0:
+        T = x.shape[-1]
+        if T <= 1:
+            return torch.nn.functional.pad(x, (0, need), mode="replicate")
+        step = min(need, T - 1)
+        x = torch.nn.functional.pad(x, (0, step), mode="reflect")
+        need -= step
+    return x
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=1003)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--books", type=int, default=8)
+    ap.add_argument("--embed", type=int, default=512)
+    ap.add_argument("--backend", default="nccl")
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if os.environ.get("MVQ_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+
+    import multimodal_vqvae_compression_audio_tactile_amd as mvq
+    from multimodal_vqvae_compression_audio_tactile_amd import dist as mdist, synth
+
+    net = mvq.build_proposed(synth.proposed_model_state(7, rvq_books=args.books, rvq_embed=args.embed),
+                             rvq_books=args.books, rvq_embed=args.embed, device=dev)
+    up_t, up_a = mvq.Resample(3000, 24000).to(dev), mvq.Resample(44100, 24000).to(dev)
+
+    # the corpus: every rank derives the same clip list from the seed and keeps the segments it owns
+    rng = np.random.default_rng(7)
+    lens24 = (rng.uniform(1.0, 4.0, args.clips) * 24000 / 320).round().astype(np.int64) * 320
+    seg_of_clip = np.ceil(lens24 / SEG).astype(np.int64)
+    first = np.concatenate([[0], np.cumsum(seg_of_clip)])
+    n_seg = int(first[-1])
+    mine = set(mdist.shard_round_robin(n_seg, rank, world))
+    a_segs, t_segs = [], []
+    t0 = time.perf_counter()
+    for c in range(args.clips):
+        ids = [i for i in range(int(first[c]), int(first[c + 1])) if i in mine]
+        if not ids:
+            continue
+        dur = lens24[c] / 24000.0
+        g = torch.Generator().manual_seed(1000 + c)
+        n3, n44 = int(round(dur * 3000)), int(round(dur * 44100))
+        t3 = torch.cumsum(torch.randn(1, n3, generator=g), -1); t3 = t3 - t3.mean(); t3 = 0.9 * t3 / t3.abs().max().clamp_min(1e-6)
+        a44 = torch.randn(1, n44, generator=g); a44 = 0.9 * a44 / a44.abs().max()
+        t24 = up_t(t3.to(dev)).clamp(-1, 1)[..., :lens24[c]]
+        a24 = up_a(a44.to(dev)).clamp(-1, 1)[..., :lens24[c]]
+        L = min(t24.shape[-1], a24.shape[-1])
+        need = int(seg_of_clip[c]) * SEG - L
+        t24, a24 = reflect_pad_right(t24[..., :L], need), reflect_pad_right(a24[..., :L], need)
+        for i in ids:
+            k = i - int(first[c])
+            a_segs.append(a24[:, k * SEG:(k + 1) * SEG]); t_segs.append(t24[:, k * SEG:(k + 1) * SEG])
+    torch.cuda.synchronize()
+    t_load = time.perf_counter() - t0
+
+    st_vals, ps_vals = [], []
+    t_fwd = t_met = 0.0
+    for s in range(0, len(a_segs), args.batch):
+        a = torch.stack(a_segs[s:s + args.batch]); t = torch.stack(t_segs[s:s + args.batch])
+        t1 = time.perf_counter()
+        y = net.forward_eval(a, t, books_use=args.books)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        Tl = min(t.shape[-1], y.shape[-1])
+        st_vals += mvq.stsim_batch(t[..., :Tl], y[..., :Tl])
+        ps_vals += mvq.psnr_3k_aligned_batch(t[..., :Tl], y[..., :Tl])
+        t3_ = time.perf_counter()
+        t_fwd += t2 - t1; t_met += t3_ - t2
+    out = {"rank": rank, "n": len(st_vals), "st": st_vals, "ps": ps_vals, "t_load": t_load, "t_fwd": t_fwd, "t_met": t_met}
+    parts = [out]
+    if dist:
+        parts = [None] * world
+        dist.all_gather_object(parts, out)
+    if rank == 0:
+        st = np.array([v for p in parts for v in p["st"]], np.float64); ps = np.array([v for p in parts for v in p["ps"]], np.float64)
+        n = int(st.size)
+        tps = 75.0
+        kbps = tps * args.books * math.log2(args.embed) / 1000.0
+        res = {"config": "synthetic corpus, round-robin segment sharding", "clips": args.clips, "segments": n_seg, "n": n,
+               "n_gpus": world, "books": args.books, "embed": args.embed, "tps": tps, "kbps": kbps,
+               "compression_ratio": PCM_KBPS_TACT_ORIG / kbps,
+               "stsim_mean": float(st.mean()), "stsim_ci95": 1.96 * float(st.std(ddof=0)) / max(1.0, math.sqrt(n)),
+               "psnr_mean": float(ps.mean()), "psnr_ci95": 1.96 * float(ps.std(ddof=0)) / max(1.0, math.sqrt(n)),
+               "seconds_max_over_ranks": {k: max(p[k] for p in parts) for k in ("t_load", "t_fwd", "t_met")},
+               "segments_per_s_forward": n / max(p["t_fwd"] for p in parts),
+               "segments_per_s_with_metrics": n / max(p["t_fwd"] + p["t_met"] for p in parts),
+               "note": "random-init weights: the PSNR / ST-SIM VALUES say nothing about codec quality; the loop, its metrics "
+                       "and the sharding are what is exercised"}
+        print(json.dumps(res), flush=True)
+    if dist:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
