@@ -49,3 +49,19 @@ def test_up_then_down_is_identity_for_band_limited_input(orc):
 def test_equal_rates_short_circuit(orc):
     x = np.arange(7, dtype=np.float32)[None]
     assert np.array_equal(orc.resample(x, 24000, 24000), x)
+
+
+def test_aligned_3k_psnr_chain_matches_reference_fixture(orc):
+    """G9 (reference align_pair_24k -> resample_f32 -> psnr_batch, with the restated resampler standing in for torchaudio):
+    the oracle's own chain reproduces it -- shifts exactly, PSNR to 1e-4 dB."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import golden_inputs as gi
+    G9 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_aligned_psnr.npz"))
+    ref, est, lags = gi.aligned_psnr_inputs()
+    for i in range(ref.shape[0]):
+        r_a, e_a, s, _ = orc.align_by_xcorr(ref[i].numpy(), est[i].numpy(), 200)
+        assert s == int(G9["shifts"][i]) == lags[i]
+        r3, e3 = orc.resample(r_a, 24000, 3000), orc.resample(e_a, 24000, 3000)
+        mse = max(float(np.mean((r3.astype(np.float64) - e3.astype(np.float64)) ** 2)), 1e-12)
+        assert abs(10.0 * math.log10(1.0 / mse) - float(G9["psnr"][i])) < 1e-4
