@@ -237,18 +237,6 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     const int n_chunks = Cin / CK;
     const bool snake_in = a.alpha_in != nullptr;
 
-#ifdef MVQ_STAGGER
-    // Two blocks share a CU (one wave each per SIMD) and run the same program: started together they stay in
-    // lock-step (both staging, then both fighting for the matrix pipe).  The block whose wave 0 sits in an odd
-    // wave slot starts a fraction of a chunk later, which de-phases the pair for the whole run.
-    {
-        if (tid == 0) reinterpret_cast<int*>(smem)[0] = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u);
-        __syncthreads();
-        const int odd = reinterpret_cast<volatile int*>(smem)[0];
-        __syncthreads();
-        if (odd) { for (int i = 0; i < MVQ_STAGGER; ++i) __builtin_amdgcn_s_sleep(64); }
-    }
-#endif
     if (snake_in) {
         for (int c = tid; c < Cin; c += C::NTHR) {
             const float al = a.alpha_in[c];
@@ -312,11 +300,9 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
-#ifdef MVQ_SCHED_GROUPS
             // operand reads of step s+1 first, then the MFMAs of step s (keeps a full k-step of latency cover)
-            __builtin_amdgcn_sched_group_barrier(0x100, MVQ_SCHED_GROUPS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
-#endif
         }
     };
 

@@ -1,10 +1,4 @@
 // conv_k7.hip -- ResidualUnit 7-tap dilated convs (75 % of the path's FLOPs) + decoder input conv.
-#ifndef MVQ_K7_TILE
-#define MVQ_K7_TILE 2, 2, 2, 2
-#endif
-#ifndef MVQ_K7_CK
-#define MVQ_K7_CK 4
-#endif
 #include "conv_dispatch.hpp"
 namespace mvq {
 template <int DIL>
@@ -14,7 +8,7 @@ static hipError_t k7(const ConvArgs& a, int bm, hipStream_t s)
         return launch_conv1d_mfma<7, 1, 1, 4, 1, 3, 4, 1, 0>(a, s);
     if (bm != 96 && conv_prefer_small_tiles(a)) return launch_conv1d_mfma<7, 1, DIL, 8, 1, 1, 2, 2, 0>(a, s);
     switch (bm) {
-        case 128: return launch_conv1d_mfma<7, 1, DIL, MVQ_K7_CK, MVQ_K7_TILE, 0>(a, s);
+        case 128: return launch_conv1d_mfma<7, 1, DIL, 4, 2, 2, 2, 2, 0>(a, s);
         case 96:  return launch_conv1d_mfma<7, 1, DIL, 4, 3, 1, 1, 4, 0>(a, s);
         case 64:  return launch_conv1d_mfma<7, 1, DIL, 8, 2, 2, 1, 4, 0>(a, s);
     }
