@@ -10,8 +10,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 dev = torch.device("cuda:0")
 layers = []   # (name, kind, Cin, Cout, ks, stride, dil, Tin, alpha_in, residual, alpha_out, count)
+import os
+UNFUSE = [int(c) for c in os.environ.get("MVQ_MB_UNFUSE", "").split(",") if c]     # time these widths as two launches
 def ru(prefix, C, T, n):
-    if C <= 128:
+    if C <= 128 and C not in UNFUSE:
         for d in (1, 3, 9):
             layers.append((f"{prefix}.RUd{d}", "r", C, C, 7, 1, d, T, True, True, False, n))
         return
