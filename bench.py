@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="1-s segments per GPU per step")
+    ap.add_argument("--torch-optim", action="store_true", help="train workload: torch.optim.AdamW + torch clip_grad_norm_ "
+                    "(the reference's own calls) instead of the fused HIP update")
     ap.add_argument("--workload", choices=["joint", "tactile", "train"], default="joint",
                     help="joint / tactile: the inference round trip (the headline metric).  train: one whole training step of "
                          "BASELINE.json configs[4] (forward_step + L1/MRSTFT/MelCos + backward + clip + AdamW + codebook EMA)")
@@ -218,7 +220,7 @@ def main():
         net.train()                                              # ctx dropout on, as in the reference's epoch loop
         crit = mvq.TrainingLoss()
         params = [p for n, p in net.named_parameters() if p.requires_grad and not n.startswith("vq.books")]
-        opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=1e-5)          # Training/...5.py:54-55,367
+        opt = (torch.optim.AdamW if args.torch_optim else mvq.optim.AdamW)(params, lr=2e-4, weight_decay=1e-5)   # ...5.py:54-55,367
 
     def step():
         if train:                                                # Training/compare_dacvsproposal_5.py:379-397
@@ -229,8 +231,12 @@ def main():
                 total.backward()
             if dist:
                 mdist.allreduce_grads(params, B)
-            torch.nn.utils.clip_grad_norm_(params, 3.0)
-            opt.step()
+            if args.torch_optim:
+                torch.nn.utils.clip_grad_norm_(params, 3.0)
+                opt.step()
+            else:
+                _, coef = mvq.optim.clip_coef(params, 3.0)      # clip_grad_norm_(params, 3.0) fused into the update
+                opt.step(clip_coef=coef)
             if dist:
                 mdist.ema_step_all_ranks(net.vq, out["r_tokens"])
             else:

@@ -279,6 +279,14 @@ int mvq_mel_max_grad_f32(const float* dden, const float* maxv, const int* argmax
 int mvq_resample_f32(const float* x, const float* kern, float* y, int batch, int len, int len_out, int orig, int newf,
                      int width, int ks, void* stream);
 
+/* Optimiser step of the training config (torch.optim.AdamW + clip_grad_norm_, Training/compare_dacvsproposal_5.py:367,394-395):
+ *   sumsq_partial : partial[n_partial] block sums of x^2 (their total is the squared gradient norm), n_partial <= 4096
+ *   adamw         : decoupled-weight-decay Adam on one tensor, torch's single-tensor operation order; clip_coef (device,
+ *                   may be NULL) multiplies the gradient on the fly; `step` is the 1-based step count (bias corrections). */
+int mvq_sumsq_partial_f32(const float* x, float* partial, int n_partial, size_t n, void* stream);
+int mvq_adamw_f32(float* p, const float* g, float* m, float* v, const float* clip_coef, size_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, void* stream);
+
 /* out = g * (1 - y*y): backward of the decoder's final tanh (y = saved output). */
 int mvq_mul_dtanh_f32(const float* g, const float* y, float* out, size_t n, void* stream);
 

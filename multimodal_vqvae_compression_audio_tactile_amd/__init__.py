@@ -8,10 +8,12 @@ Drop-in surface:
   * ``safe_l1`` / ``MultiResSTFTLoss`` / ``MelCosineLoss`` / ``TrainingLoss`` -- the training losses (losses.py) and
     ``train`` -- the HIP-backed autograd Functions behind ``AllPredAR.forward_step(...); total.backward()``;
   * ``Resample`` / ``resample_to`` -- torchaudio.transforms.Resample as the reference calls it; ``stsim_batch``;
+  * ``optim`` -- ``AdamW`` / ``clip_grad_norm_`` with torch's call shapes on HIP kernels (the reference's own
+    ``torch.optim.AdamW`` works on the modules as well);
   * ``ops`` -- tensor-level wrappers over the C ABI (include/mvq.h), ``synth`` -- seeded weights / signals.
 All compute runs in libmvq_hip.so (hand-written HIP for gfx950); there is no CPU fallback.
 """
-from . import ops, synth, train  # noqa: F401
+from . import ops, optim, synth, train  # noqa: F401
 from .resample import Resample, resample_to  # noqa: F401
 from .losses import MelCosineLoss, MultiResSTFTLoss, TrainingLoss, safe_l1, stsim_batch  # noqa: F401
 from ._lib import MvqError, build, lib  # noqa: F401

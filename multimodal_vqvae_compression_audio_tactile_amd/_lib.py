@@ -64,6 +64,8 @@ EXPORTS = {
     "mvq_mel_cos_f32": (c_int, [c_void_p] * 5 + [c_float] + [c_int] * 3 + [c_size_t, c_float, c_int, c_void_p]),
     "mvq_mel_max_grad_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p]),
     "mvq_resample_f32": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
+    "mvq_sumsq_partial_f32": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    "mvq_adamw_f32": (c_int, [c_void_p] * 5 + [c_size_t] + [c_float] * 5 + [c_int, c_void_p]),
     "mvq_gelu_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvq_sub3d_f32": (c_int, [c_void_p, c_size_t, c_size_t] * 3 + [c_int] * 3 + [c_void_p]),
     "mvq_copy3d_f32": (c_int, [c_void_p, c_size_t, c_size_t] * 2 + [c_int] * 3 + [c_void_p]),

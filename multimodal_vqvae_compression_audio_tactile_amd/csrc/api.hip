@@ -1,6 +1,7 @@
 // api.hip -- the C ABI of libmvq_hip.so (declared in include/mvq.h): argument checks and kernel dispatch.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 #include "../../include/mvq.h"
@@ -564,6 +565,23 @@ int mvq_resample_f32(const float* x, const float* kern, float* y, int batch, int
     if (!x || !kern || !y) return fail(MVQ_EINVAL, "resample: null tensor");
     hipError_t e = mvq::launch_resample(x, kern, y, batch, len, len_out, orig, newf, width, ks, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "resample");
+}
+
+int mvq_sumsq_partial_f32(const float* x, float* partial, int n_partial, size_t n, void* stream)
+{
+    if (!partial || n_partial <= 0 || n_partial > 4096 || (!x && n)) return fail(MVQ_EINVAL, "sumsq_partial: bad argument");
+    hipError_t e = mvq::launch_sumsq_partial(x, partial, n_partial, n, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "sumsq_partial");
+}
+
+int mvq_adamw_f32(float* p, const float* g, float* m, float* v, const float* clip_coef, size_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, void* stream)
+{
+    if (step < 1 || beta1 < 0 || beta1 >= 1 || beta2 < 0 || beta2 >= 1) return fail(MVQ_EINVAL, "adamw: bad hyper-parameter");
+    if ((!p || !g || !m || !v) && n) return fail(MVQ_EINVAL, "adamw: null tensor");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipError_t e = mvq::launch_adamw(p, g, m, v, clip_coef, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "adamw");
 }
 
 int mvq_mul_dtanh_f32(const float* g, const float* y, float* out, size_t n, void* stream)

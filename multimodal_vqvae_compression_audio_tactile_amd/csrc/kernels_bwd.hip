@@ -282,4 +282,55 @@ hipError_t launch_rowsum(const float* in, float* out, int rows, int cols, int ac
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// optimiser step of the training config (torch.optim.AdamW as the reference builds it, Training/compare_dacvsproposal_5.py:
+// 367; clip_grad_norm_ at ...:394): partial sums of squares for the global gradient norm, and the decoupled-weight-decay
+// Adam update with the clip factor applied to the gradient on the fly.  Same operation order as torch's single-tensor
+// AdamW:  p *= 1 - lr*wd;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, size_t n)
+{
+    __shared__ float red[256];
+    float a = 0.0f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a = dfma(x[i], x[i], a);
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+hipError_t launch_sumsq_partial(const float* x, float* partial, int n_partial, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)n_partial), dim3(256), 0, s, x, partial, n);
+    return hipGetLastError();
+}
+
+// clip_coef[0] (device): factor the gradients are multiplied by (min(1, max_norm/(norm + 1e-6)), or 1 when NULL)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             const float* __restrict__ clip_coef, size_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, float bc1, float sqrt_bc2)
+{
+    const float cc = clip_coef ? clip_coef[0] : 1.0f;
+    const float step = lr / bc1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * cc;
+        float pi = p[i] * (1.0f - lr * weight_decay);
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;               // lerp form used by torch: m + (g - m)*(1-b1)
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        const float denom = __builtin_sqrtf(vi) / sqrt_bc2 + eps;
+        pi = pi - step * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, const float* clip_coef, size_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, float bc1, float sqrt_bc2, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, clip_coef, n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, sqrt_bc2);
+    return hipGetLastError();
+}
+
 }  // namespace mvq

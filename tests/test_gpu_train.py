@@ -276,3 +276,34 @@ def test_reference_step_under_autocast_and_gradscaler(dev):
     tot = safe_l1(out["y_hat"], out["tgt"])
     tot.backward()
     assert torch.isfinite(tot) and all(torch.isfinite(p.grad).all() for n, p in net.named_parameters() if p.grad is not None)
+
+
+def test_fused_adamw_and_clip_match_torch(dev):
+    """optim.AdamW / clip_grad_norm_ against torch.optim.AdamW / torch.nn.utils.clip_grad_norm_ over several steps (the
+    reference's hyper-parameters: lr 2e-4, weight decay 1e-5, clip 3.0; Training/compare_dacvsproposal_5.py:54-56)."""
+    from multimodal_vqvae_compression_audio_tactile_amd import optim
+    g = torch.Generator().manual_seed(5)
+    shapes = [(1024, 1024), (96, 1024, 1), (1024,), ()]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    pa = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    pb = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    oa = optim.AdamW(pa, lr=2e-4, weight_decay=1e-5)
+    ob = torch.optim.AdamW(pb, lr=2e-4, weight_decay=1e-5)
+    for step in range(6):
+        grads = [(3.0 if step % 2 else 0.01) * torch.randn(s, generator=g) for s in shapes]     # clipped on odd steps only
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad = gr.clone().to(dev); q.grad = gr.clone().to(dev)
+        if step < 3:                                                   # separate clip, then step
+            na = optim.clip_grad_norm_(pa, 3.0)
+            nb = torch.nn.utils.clip_grad_norm_(pb, 3.0)
+            oa.step()
+        else:                                                          # clip fused into the update
+            na, coef = optim.clip_coef(pa, 3.0)
+            nb = torch.nn.utils.clip_grad_norm_(pb, 3.0)
+            oa.step(clip_coef=coef)
+        ob.step()
+        assert abs(float(na) - float(nb)) <= 1e-5 * float(nb)
+        v0 = pa[0]._version
+        for p, q in zip(pa, pb):
+            assert torch.allclose(p, q, rtol=1e-6, atol=1e-7), step
+    assert pa[0]._version > 0 and v0 == pa[0]._version
