@@ -65,18 +65,20 @@ class KernelEvents:
         orig_conv, orig_tr, orig_ru = ops.conv1d, ops.conv_transpose1d, ops.residual_unit_fused
         rec = self.records
 
-        def residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, alpha_dual=None):
+        # algorithmic flops count TRUE columns only (zero-padded rows: tvalid / tout_rows, include/mvq.h)
+        def residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, alpha_dual=None, tvalid=0):
             B, c, t = x.shape
+            t = tvalid or t
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            y = orig_ru(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next, alpha_dual)
+            y = orig_ru(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next, alpha_dual, tvalid)
             e1.record()
             rec.append((ops.residual_unit_kernel_name(c, dil), 2.0 * c * c * 8 * t * B, e0, e1))
             return y
 
         def conv1d(x, wp, cout, ks, bias=None, stride=1, dil=1, pad=0, **kw):
             B, cin, tin = x.shape
-            tout = ops.conv1d_out_len(tin, ks, stride, dil, pad)
+            tout = kw.get("tvalid") or ops.conv1d_out_len(tin, ks, stride, dil, pad)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             y = orig_conv(x, wp, cout, ks, bias=bias, stride=stride, dil=dil, pad=pad, **kw)
@@ -86,12 +88,14 @@ class KernelEvents:
 
         def conv_transpose1d(x, wp, cout, stride, pad, **kw):
             B, cin, tin = x.shape
+            t_out = kw.get("tvalid") or kw.get("tout_rows") or ((tin - 1) * stride - 2 * pad + 2 * stride)
+            tin_true = (t_out + 2 * pad - 2 * stride) // stride + 1
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             y = orig_tr(x, wp, cout, stride, pad, **kw)
             e1.record()
             rec.append((ops.conv_kernel_name(cin, cout, 2 * stride, stride, 1, transposed=True, tin=tin, batch=B),
-                        2.0 * cin * cout * 2 * stride * tin * B, e0, e1))
+                        2.0 * cin * cout * 2 * stride * tin_true * B, e0, e1))
             return y
 
         ops.conv1d, ops.conv_transpose1d, ops.residual_unit_fused = conv1d, conv_transpose1d, residual_unit_fused

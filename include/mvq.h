@@ -271,6 +271,25 @@ int mvq_mel_cos_f32(const float* mel, const float* maxv, float* cosv, float* dme
 int mvq_mel_max_grad_f32(const float* dden, const float* maxv, const int* argmax, float* dmel, int batch, int nframes, float eps,
                          void* stream);
 
+/* Zero-padded rows.  A layer whose natural length is not a multiple of 4 (the decoder's 2 999-sample block) would take
+ * the 4-byte load / store paths.  Instead its tensors are allocated with rows rounded up to a multiple of 4 and the tail kept
+ * at ZERO, which is exactly the zero padding a conv sees beyond the end of its input: every kernel then runs its 16-byte
+ * paths and the results of the true columns are bit-identical.  `tvalid` = true length: output columns >= tvalid are
+ * written as zeros (0 = all columns are data).  conv_transpose1d: `tout_rows` = row length of y (0 = natural; smaller when
+ * the input carried a zero tail; up to `pad` larger with tvalid <= natural).  MFMA-tiled shapes only. */
+int mvq_conv1d_padded_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                          const float* residual, const float* alpha_out, float* y, float* y2, const float* alpha2,
+                          int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act, int tvalid,
+                          void* stream);
+int mvq_residual_unit_padded_f32(const float* x, const float* x_snaked, const float* w7p, const float* b7,
+                                 const float* alpha_a, const float* alpha_b, const float* w1p, const float* b1,
+                                 const float* alpha_next, float* y, float* y2, const float* alpha2, float* scratch,
+                                 int batch, int c, int t, int dil, int tvalid, void* stream);
+int mvq_conv_transpose1d_padded_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                                    const float* alpha_out, float* y, float* y2, const float* alpha2,
+                                    int batch, int cin, int tin, int cout, int stride, int pad, int tout_rows, int tvalid,
+                                    void* stream);
+
 /* Polyphase sinc resampler: torchaudio.transforms.Resample(orig, new) as the reference
  * calls it on every file (Training/compare_dacvsproposal_5.py:110-113, Evaluation/dac_vcpwq_proposed6_latency.py:151-156).
  * orig/newf are the rates divided by their gcd, kern[newf][ks] the filter bank (ks = 2*width + orig),

@@ -140,7 +140,15 @@ int mvq_conv1d_dual_f32(const float* x, const float* wp, const float* bias, cons
                         const float* residual, const float* alpha_out, float* y, float* y2, const float* alpha2,
                         int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act, void* stream)
 {
+    return mvq_conv1d_padded_f32(x, wp, bias, alpha_in, residual, alpha_out, y, y2, alpha2, batch, cin, tin, cout, ks, stride,
+                                 dil, pad, act, 0, stream);
+}
 
+int mvq_conv1d_padded_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                          const float* residual, const float* alpha_out, float* y, float* y2, const float* alpha2,
+                          int batch, int cin, int tin, int cout, int ks, int stride, int dil, int pad, int act, int tvalid,
+                          void* stream)
+{
     if (batch < 0 || cin <= 0 || cout <= 0 || tin < 0 || ks <= 0 || stride <= 0 || dil <= 0 || pad < 0)
         return fail(MVQ_EINVAL, "conv1d: bad shape B=%d Cin=%d Tin=%d Cout=%d ks=%d s=%d d=%d p=%d", batch, cin, tin, cout, ks, stride, dil, pad);
     if (act != MVQ_ACT_NONE && act != MVQ_ACT_TANH) return fail(MVQ_EINVAL, "conv1d: bad act %d", act);
@@ -148,14 +156,17 @@ int mvq_conv1d_dual_f32(const float* x, const float* wp, const float* bias, cons
     if (batch == 0 || tout == 0) return MVQ_OK;
     if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv1d: null tensor");
     if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "conv1d: y2 and alpha2 go together");
+    if (tvalid < 0 || tvalid > tout) return fail(MVQ_EINVAL, "conv1d: tvalid %d outside [0, %d]", tvalid, tout);
     const int mpad = mvq::conv_mpad(cout);
 
     mvq::ConvArgs a{};
     a.x = x; a.wp = wp; a.bias = bias; a.alpha_in = alpha_in; a.residual = residual; a.alpha_out = alpha_out; a.y = y;
     a.B = batch; a.Cin = cin; a.Tin = tin; a.Cout = cout; a.Tout = tout; a.pad = pad; a.Mpad = mpad;
     a.Mrows = cout; a.Ncols = tout; a.act = act; a.up_s = 1; a.up_p = 0; a.y2 = y2; a.alpha2 = alpha2;
+    a.tvalid = (tvalid == tout) ? 0 : tvalid;
 
     hipError_t e = dispatch_conv1d(a, ks, stride, dil, S(stream));
+    if (e == hipErrorInvalidValue && a.tvalid) return fail(MVQ_EUNSUPPORTED, "conv1d: zero-padded rows need an MFMA-tiled shape");
     if (e == hipErrorInvalidValue) {
         (void)hipGetLastError();
         mvq::DirectConvArgs d{x, wp, bias, alpha_in, residual, alpha_out, y, batch, cin, tin, cout, tout, ks, stride, dil, pad, mpad, act, y2, alpha2, nullptr, nullptr};
@@ -203,7 +214,17 @@ int mvq_residual_unit_dual_f32(const float* x, const float* x_snaked, const floa
                                const float* alpha_next, float* y, float* y2, const float* alpha2, float* scratch,
                                int batch, int c, int t, int dil, void* stream)
 {
+    return mvq_residual_unit_padded_f32(x, x_snaked, w7p, b7, alpha_a, alpha_b, w1p, b1, alpha_next, y, y2, alpha2, scratch,
+                                        batch, c, t, dil, 0, stream);
+}
+
+int mvq_residual_unit_padded_f32(const float* x, const float* x_snaked, const float* w7p, const float* b7,
+                                 const float* alpha_a, const float* alpha_b, const float* w1p, const float* b1,
+                                 const float* alpha_next, float* y, float* y2, const float* alpha2, float* scratch,
+                                 int batch, int c, int t, int dil, int tvalid, void* stream)
+{
     if (batch < 0 || c <= 0 || t < 0 || dil <= 0) return fail(MVQ_EINVAL, "residual_unit: bad shape");
+    if (tvalid < 0 || tvalid > t) return fail(MVQ_EINVAL, "residual_unit: tvalid outside [0, t]");
     if (batch == 0 || t == 0) return MVQ_OK;
     if (!x || !w7p || !w1p || !alpha_a || !alpha_b || !y) return fail(MVQ_EINVAL, "residual_unit: null tensor");
     if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "residual_unit: y2 and alpha2 go together");
@@ -213,15 +234,16 @@ int mvq_residual_unit_dual_f32(const float* x, const float* x_snaked, const floa
         a.B = batch; a.Cin = c; a.Tin = t; a.Cout = c; a.Tout = t; a.pad = 3 * dil; a.Mpad = mvq::conv_mpad(c);
         a.Mrows = c; a.Ncols = t; a.act = 0; a.up_s = 1; a.up_p = 0;
         a.alpha_mid = alpha_b; a.w2p = w1p; a.bias2 = b1; a.y2 = y2; a.alpha2 = alpha2;
+        a.tvalid = (tvalid == t) ? 0 : tvalid;
         hipError_t e = mvq::launch_residual_unit_fused(a, dil, S(stream));
         return e == hipSuccess ? MVQ_OK : hipfail(e, "residual_unit(fused)");
     }
     if (!scratch) return fail(MVQ_EINVAL, "residual_unit: scratch required for C=%d (see mvq_residual_unit_scratch_floats)", c);
-    int rc = x_snaked
-        ? mvq_conv1d_f32(x_snaked, w7p, b7, nullptr, nullptr, alpha_b, scratch, batch, c, t, c, 7, 1, dil, 3 * dil, MVQ_ACT_NONE, stream)
-        : mvq_conv1d_f32(x, w7p, b7, alpha_a, nullptr, alpha_b, scratch, batch, c, t, c, 7, 1, dil, 3 * dil, MVQ_ACT_NONE, stream);
+    int rc = mvq_conv1d_padded_f32(x_snaked ? x_snaked : x, w7p, b7, x_snaked ? nullptr : alpha_a, nullptr, alpha_b, scratch,
+                                   nullptr, nullptr, batch, c, t, c, 7, 1, dil, 3 * dil, MVQ_ACT_NONE, tvalid, stream);
     if (rc != MVQ_OK) return rc;
-    return mvq_conv1d_dual_f32(scratch, w1p, b1, nullptr, x, alpha_next, y, y2, alpha2, batch, c, t, c, 1, 1, 1, 0, MVQ_ACT_NONE, stream);
+    return mvq_conv1d_padded_f32(scratch, w1p, b1, nullptr, x, alpha_next, y, y2, alpha2, batch, c, t, c, 1, 1, 1, 0,
+                                 MVQ_ACT_NONE, tvalid, stream);
 }
 
 int mvq_conv_transpose1d_dual_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
@@ -239,10 +261,24 @@ int mvq_conv_transpose1d_dual_f32(const float* x, const float* wp, const float* 
                                   const float* alpha_out, float* y, float* y2, const float* alpha2,
                                   int batch, int cin, int tin, int cout, int stride, int pad, void* stream)
 {
+    return mvq_conv_transpose1d_padded_f32(x, wp, bias, alpha_in, alpha_out, y, y2, alpha2, batch, cin, tin, cout, stride, pad,
+                                           0, 0, stream);
+}
 
+int mvq_conv_transpose1d_padded_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                                    const float* alpha_out, float* y, float* y2, const float* alpha2,
+                                    int batch, int cin, int tin, int cout, int stride, int pad, int tout_rows, int tvalid,
+                                    void* stream)
+{
     if (batch < 0 || cin <= 0 || cout <= 0 || tin < 0 || stride <= 0 || pad < 0)
         return fail(MVQ_EINVAL, "conv_transpose1d: bad shape");
-    const int tout = (tin - 1) * stride - 2 * pad + 2 * stride;
+    const int tnat = (tin - 1) * stride - 2 * pad + 2 * stride;
+    /* tout_rows: length of the output rows (0 = the natural length).  Shorter than natural: the input carries a zero tail and
+     * only its true outputs are wanted.  Up to `pad` longer (the polyphase form visits those columns too): rows padded to a
+     * multiple of 4, columns >= tvalid zeroed. */
+    const int tout = tout_rows > 0 ? tout_rows : tnat;
+    if (tout > tnat + pad || tvalid < 0 || tvalid > tout || (tout > tnat && (tvalid == 0 || tvalid > tnat)))
+        return fail(MVQ_EINVAL, "conv_transpose1d: tout_rows %d / tvalid %d inconsistent with the natural length %d", tout, tvalid, tnat);
     if (batch == 0 || tin == 0 || tout <= 0) return MVQ_OK;
     if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv_transpose1d: null tensor");
     if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "conv_transpose1d: y2 and alpha2 go together");
@@ -254,8 +290,10 @@ int mvq_conv_transpose1d_dual_f32(const float* x, const float* wp, const float* 
         a.x = x; a.wp = wp; a.bias = bias; a.alpha_in = alpha_in; a.residual = nullptr; a.alpha_out = alpha_out; a.y = y;
         a.B = batch; a.Cin = cin; a.Tin = tin; a.Cout = cout; a.Tout = tout; a.pad = 1; a.Mpad = mpad;
         a.Mrows = mrows; a.Ncols = tin + 1; a.act = 0; a.up_s = stride; a.up_p = pad; a.y2 = y2; a.alpha2 = alpha2;
+        a.tvalid = (tvalid == tout) ? 0 : tvalid;
         e = dispatch_convtr(a, S(stream));
     }
+    if (e == hipErrorInvalidValue && (tvalid || tout_rows)) return fail(MVQ_EUNSUPPORTED, "conv_transpose1d: zero-padded rows need an MFMA-tiled shape");
     if (e == hipErrorInvalidValue) {
         (void)hipGetLastError();
         mvq::DirectConvArgs d{x, wp, bias, alpha_in, nullptr, alpha_out, y, batch, cin, tin, cout, tout, 2 * stride, stride, 1, pad, mpad, 0, y2, alpha2, nullptr, nullptr};

@@ -60,6 +60,9 @@ struct ConvArgs {
     // front, fused behind the input-gradient conv; dsn_src[B,Cout,Tout] is that Snake's saved input, dsn_alpha[Cout].
     const float* dsn_src;
     const float* dsn_alpha;
+    int tvalid;             // > 0: rows are zero-padded beyond their true length (a multiple-of-4 row length keeps every
+                            // load / store 16-byte aligned): output columns >= tvalid are written as zeros, so the tail stays
+                            // a valid zero padding for the next conv.  0: every column is data.
     char* name_out;         // host only: when set, launchers write the kernel instantiation name here and do not launch
     int name_len;
 };
@@ -410,9 +413,10 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     const bool ok = mok && n < a.Ncols && t >= 0 && t < a.Tout;
                     t = ok ? t : 0;
                     float v = acc[i][j][r] + bv;
-                    if (ok && a.y2) { const float a2 = a.alpha2[co]; a.y2[rowoff + t] = det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
+                    const bool tail = a.tvalid && t >= a.tvalid;
+                    if (ok && a.y2) { const float a2 = a.alpha2[co]; a.y2[rowoff + t] = tail ? 0.0f : det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
                     if (snake_out) v = det_snake(v, al, inv);
-                    if (ok) a.y[rowoff + t] = v;
+                    if (ok) a.y[rowoff + t] = tail ? 0.0f : v;
                 }
             }
         }
@@ -465,9 +469,11 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                         const f32x4 rv = *reinterpret_cast<const f32x4*>(a.residual + off);
                         v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
                     }
+                    const int nz = (a.tvalid && n + 4 > a.tvalid) ? n + 4 - a.tvalid : 0;     // trailing pad columns of this quad
                     if (a.y2) {
                         const float a2 = a.alpha2[m], i2 = 1.0f / (a2 + 1e-9f);
                         f32x4 w = {det_snake(v.x, a2, i2), det_snake(v.y, a2, i2), det_snake(v.z, a2, i2), det_snake(v.w, a2, i2)};
+                        if (nz > 0) { w.w = 0.0f; if (nz > 1) w.z = 0.0f; if (nz > 2) w.y = 0.0f; if (nz > 3) w.x = 0.0f; }
                         *reinterpret_cast<f32x4*>(a.y2 + off) = w;
                     }
                     if (snake_out) {
@@ -476,6 +482,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                         v.z = det_snake(v.z, al, inv); v.w = det_snake(v.w, al, inv);
                     }
                     if (do_tanh) { v.x = det_tanh(v.x); v.y = det_tanh(v.y); v.z = det_tanh(v.z); v.w = det_tanh(v.w); }
+                    if (nz > 0) { v.w = 0.0f; if (nz > 1) v.z = 0.0f; if (nz > 2) v.y = 0.0f; if (nz > 3) v.x = 0.0f; }
                     *reinterpret_cast<f32x4*>(a.y + off) = v;
                 }
             }
@@ -491,10 +498,11 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     float v = Ct[row * C::BNP + col] + (ep_bias ? ep_bias[m] : 0.0f);
                     if (a.dsn_src) { const float ad = a.dsn_alpha[m]; v = v * det_dsnake(a.dsn_src[off], ad, 1.0f / (ad + 1e-9f)); }
                     if (has_res) v = v + a.residual[off];
-                    if (a.y2) { const float a2 = a.alpha2[m]; a.y2[off] = det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
+                    const bool tail = a.tvalid && n >= a.tvalid;
+                    if (a.y2) { const float a2 = a.alpha2[m]; a.y2[off] = tail ? 0.0f : det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
                     if (snake_out) { const float al = a.alpha_out[m]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
                     if (do_tanh) v = det_tanh(v);
-                    a.y[off] = v;
+                    a.y[off] = tail ? 0.0f : v;
                 }
             }
         }
@@ -515,9 +523,10 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             if (co < a.Cout && n0 + nl < a.Ncols && t >= 0 && t < a.Tout) {
                 float v = Ct[(col * S + rr) * C::BNP + nl] + (ep_bias ? ep_bias[co] : 0.0f);
                 const size_t off = ((size_t)b * a.Cout + co) * a.Tout + t;
-                if (a.y2) { const float a2 = a.alpha2[co]; a.y2[off] = det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
+                const bool tail = a.tvalid && t >= a.tvalid;
+                if (a.y2) { const float a2 = a.alpha2[co]; a.y2[off] = tail ? 0.0f : det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
                 if (snake_out) { const float al = a.alpha_out[co]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
-                a.y[off] = v;
+                a.y[off] = tail ? 0.0f : v;
             }
         }
     }

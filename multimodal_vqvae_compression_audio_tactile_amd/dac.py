@@ -91,10 +91,10 @@ class WNConv1d(nn.Module):
         return ops.conv1d_dgrad(gy, self.packed_dgrad(), self.cin, tin, self.ks, 1, self.dilation, self.padding,
                                 dsnake_src=dsnake_src, dsnake_alpha=dsnake_alpha, residual=residual)
 
-    def run(self, x, alpha_in=None, residual=None, alpha_out=None, tanh=False, alpha_dual=None):
+    def run(self, x, alpha_in=None, residual=None, alpha_out=None, tanh=False, alpha_dual=None, tvalid=0):
         return ops.conv1d(x, self.packed(), self.cout, self.ks, bias=self.bias.detach(), stride=self.stride,
                           dil=self.dilation, pad=self.padding, alpha_in=alpha_in, residual=residual,
-                          alpha_out=alpha_out, tanh=tanh, alpha_dual=alpha_dual)
+                          alpha_out=alpha_out, tanh=tanh, alpha_dual=alpha_dual, tvalid=tvalid)
 
     def forward(self, x):
         return self.run(x)
@@ -129,9 +129,10 @@ class WNConvTranspose1d(nn.Module):
         return ops.conv1d_dgrad(gy, self.packed_dgrad(), self.cin, tin, self.ks, self.stride, 1, self.padding,
                                 dsnake_src=dsnake_src, dsnake_alpha=dsnake_alpha)
 
-    def run(self, x, alpha_in=None, alpha_out=None, alpha_dual=None):
+    def run(self, x, alpha_in=None, alpha_out=None, alpha_dual=None, tout_rows=0, tvalid=0):
         return ops.conv_transpose1d(x, self.packed(), self.cout, self.stride, self.padding, bias=self.bias.detach(),
-                                    alpha_in=alpha_in, alpha_out=alpha_out, alpha_dual=alpha_dual)
+                                    alpha_in=alpha_in, alpha_out=alpha_out, alpha_dual=alpha_dual, tout_rows=tout_rows,
+                                    tvalid=tvalid)
 
     def forward(self, x):
         return self.run(x)
@@ -153,11 +154,11 @@ class ResidualUnit(nn.Module):
     def wants_presnaked(self) -> bool:
         return self.block[1].cin > 128
 
-    def run(self, x, alpha_next=None, x_snaked=None, alpha_dual=None):
+    def run(self, x, alpha_next=None, x_snaked=None, alpha_dual=None, tvalid=0):
         c7, c1 = self.block[1], self.block[3]
         return ops.residual_unit(x, c7.packed(), c7.bias.detach(), self.block[0].flat(), self.block[2].flat(),
                                  c1.packed(), c1.bias.detach(), c7.dilation, alpha_next=alpha_next, x_snaked=x_snaked,
-                                 alpha_dual=alpha_dual)
+                                 alpha_dual=alpha_dual, tvalid=tvalid)
 
     def forward(self, x):
         return self.run(x)
@@ -223,19 +224,33 @@ class DecoderBlock(nn.Module):
                                    WNConvTranspose1d(input_dim, output_dim, 2 * stride, stride, math.ceil(stride / 2)),
                                    ResidualUnit(output_dim, 1), ResidualUnit(output_dim, 3), ResidualUnit(output_dim, 9))
 
-    def run(self, x, alpha_next=None, pre_snaked=False):
-        """`pre_snaked`: x already carries this block's leading Snake (fused into its producer's epilogue)."""
-        r0, r1, r2 = self.block[2], self.block[3], self.block[4]
+    def run(self, x, alpha_next=None, pre_snaked=False, t_in=None):
+        """`pre_snaked`: x already carries this block's leading Snake (fused into its producer's epilogue).
+        `t_in`: true length of x's rows when they carry a zero tail (zero-padded rows, include/mvq.h); with it the call
+        returns (y, true length of y) and y's rows are themselves padded to a multiple of 4 where the kernels allow."""
+        up, r0, r1, r2 = self.block[1], self.block[2], self.block[3], self.block[4]
         a_in = None if pre_snaked else self.block[0].flat()
+        rows, tv = 0, 0
+        if t_in is not None:
+            s_, p_ = up.stride, up.padding
+            tn = (t_in - 1) * s_ - 2 * p_ + 2 * s_                       # true output length
+            tnat = (x.shape[-1] - 1) * s_ - 2 * p_ + 2 * s_              # what the (possibly padded) input rows would give
+            tp = (tn + 3) // 4 * 4
+            can_pad = tp != tn and tp <= tnat + p_ and up.cin % 32 == 0 and up.cout % 32 == 0
+            rows = tp if can_pad else tn
+            tv = tn if can_pad else 0
+            rows = 0 if (rows == tnat and tv == 0) else rows
         if r0.wants_presnaked():
-            h, hs = self.block[1].run(x, alpha_in=a_in, alpha_dual=r0.block[0].flat())
-            h, hs = r0.run(h, x_snaked=hs, alpha_dual=r1.block[0].flat())
-            h, hs = r1.run(h, x_snaked=hs, alpha_dual=r2.block[0].flat())
-            return r2.run(h, x_snaked=hs, alpha_next=alpha_next)
-        h = self.block[1].run(x, alpha_in=a_in)
-        h = r0.run(h)
-        h = r1.run(h)
-        return r2.run(h, alpha_next=alpha_next)
+            h, hs = up.run(x, alpha_in=a_in, alpha_dual=r0.block[0].flat(), tout_rows=rows, tvalid=tv)
+            h, hs = r0.run(h, x_snaked=hs, alpha_dual=r1.block[0].flat(), tvalid=tv)
+            h, hs = r1.run(h, x_snaked=hs, alpha_dual=r2.block[0].flat(), tvalid=tv)
+            y = r2.run(h, x_snaked=hs, alpha_next=alpha_next, tvalid=tv)
+        else:
+            h = up.run(x, alpha_in=a_in, tout_rows=rows, tvalid=tv)
+            h = r0.run(h, tvalid=tv)
+            h = r1.run(h, tvalid=tv)
+            y = r2.run(h, alpha_next=alpha_next, tvalid=tv)
+        return y if t_in is None else (y, tn)
 
     def forward(self, x):
         return self.run(x)
@@ -308,11 +323,20 @@ class Decoder(nn.Module):
     def _forward_fast(self, z):
         m = self.model
         nblk = len(m) - 4
-        h = m[0].run(z, alpha_out=m[1].block[0].flat())
+        # Rows whose length is not a multiple of 4 (75 latent frames, the 2 999-sample block) are carried zero-padded to the
+        # next multiple of 4 so that every layer runs its 16-byte load / store paths (include/mvq.h "Zero-padded rows").
+        t = z.shape[-1]
+        tv = 0
+        if t % 4 and t > 0 and m[0].cin % 32 == 0:
+            zp = torch.zeros(z.shape[0], z.shape[1], (t + 3) // 4 * 4, device=z.device, dtype=torch.float32)
+            zp[..., :t] = z
+            z, tv = zp, t
+        h = m[0].run(z, alpha_out=m[1].block[0].flat(), tvalid=tv)
         for i in range(1, nblk + 1):
             nxt = m[i + 1].block[0].flat() if i < nblk else m[nblk + 1].flat()
-            h = m[i].run(h, alpha_next=nxt, pre_snaked=True)
-        return m[nblk + 2].run(h, tanh=True)
+            h, t = m[i].run(h, alpha_next=nxt, pre_snaked=True, t_in=t)
+        y = m[nblk + 2].run(h, tanh=True)
+        return y if y.shape[-1] == t else y[..., :t].contiguous()
 
 
 class _DecoderInputGrad(torch.autograd.Function):

@@ -79,8 +79,9 @@ def pack_conv_transpose1d(w: torch.Tensor, stride: int) -> torch.Tensor:
 
 
 def conv1d(x, wp, cout, ks, bias=None, stride=1, dil=1, pad=0, alpha_in=None, residual=None, alpha_out=None,
-           tanh=False, out=None, alpha_dual=None):
-    """alpha_dual: also return snake(y_raw, alpha_dual) (the next ResidualUnit's Snake, hoisted): -> (y, y2)."""
+           tanh=False, out=None, alpha_dual=None, tvalid=0):
+    """alpha_dual: also return snake(y_raw, alpha_dual) (the next ResidualUnit's Snake, hoisted): -> (y, y2).
+    tvalid: rows are zero-padded beyond column tvalid (see include/mvq.h "Zero-padded rows"); 0 = plain tensors."""
     x = _dev(x, "x")
     B, cin, tin = x.shape
     tout = conv1d_out_len(tin, ks, stride, dil, pad)
@@ -91,9 +92,9 @@ def conv1d(x, wp, cout, ks, bias=None, stride=1, dil=1, pad=0, alpha_in=None, re
         residual = _dev(residual, "residual")
         if tuple(residual.shape) != (B, cout, tout):
             raise MvqError(f"conv1d: residual shape {tuple(residual.shape)} != {(B, cout, tout)}")
-    check(_lib.lib().mvq_conv1d_dual_f32(x.data_ptr(), wp.data_ptr(), _p(bias), _p(alpha_in), _p(residual),
-                                         _p(alpha_out), out.data_ptr(), _p(y2), _p(alpha_dual), B, cin, tin, cout, ks,
-                                         stride, dil, pad, 1 if tanh else 0, _stream()), "mvq_conv1d_f32")
+    check(_lib.lib().mvq_conv1d_padded_f32(x.data_ptr(), wp.data_ptr(), _p(bias), _p(alpha_in), _p(residual),
+                                           _p(alpha_out), out.data_ptr(), _p(y2), _p(alpha_dual), B, cin, tin, cout, ks,
+                                           stride, dil, pad, 1 if tanh else 0, int(tvalid), _stream()), "mvq_conv1d_f32")
     return out if alpha_dual is None else (out, y2)
 
 
@@ -104,19 +105,19 @@ def residual_unit_kernel_name(c, dil) -> str:
     return buf.value.decode()
 
 
-def residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, alpha_dual=None):
+def residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, alpha_dual=None, tvalid=0):
     """The single-launch form (C in {64, 96, 128})."""
     B, C, T = x.shape
     y = torch.empty_like(x)
     y2 = torch.empty_like(x) if alpha_dual is not None else None
-    check(_lib.lib().mvq_residual_unit_dual_f32(x.data_ptr(), None, w7p.data_ptr(), _p(b7), alpha_a.data_ptr(),
-                                                alpha_b.data_ptr(), w1p.data_ptr(), _p(b1), _p(alpha_next), y.data_ptr(),
-                                                _p(y2), _p(alpha_dual), None, B, C, T, dil, _stream()),
+    check(_lib.lib().mvq_residual_unit_padded_f32(x.data_ptr(), None, w7p.data_ptr(), _p(b7), alpha_a.data_ptr(),
+                                                  alpha_b.data_ptr(), w1p.data_ptr(), _p(b1), _p(alpha_next), y.data_ptr(),
+                                                  _p(y2), _p(alpha_dual), None, B, C, T, dil, int(tvalid), _stream()),
           "mvq_residual_unit_f32")
     return y if alpha_dual is None else (y, y2)
 
 
-def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x_snaked=None, alpha_dual=None):
+def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x_snaked=None, alpha_dual=None, tvalid=0):
     """x + conv1(snake(conv7_dil(snake(x)))) (+ the next Snake1d): one fused launch for C in {64,96,128}, else the
     two conv launches (Snake on load / on store in the first, skip + next Snake in the second's epilogue).
     x_snaked: snake_a(x) already produced by the previous layer's dual output (skips the staging-time Snake);
@@ -124,23 +125,25 @@ def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x
     x = _dev(x, "x")
     B, C, T = x.shape
     if _lib.lib().mvq_residual_unit_scratch_floats(B, C, T, dil) == 0:
-        return residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next, alpha_dual)
+        return residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next, alpha_dual, tvalid)
     if x_snaked is not None:
-        h = conv1d(x_snaked, w7p, C, 7, bias=b7, dil=dil, pad=3 * dil, alpha_out=alpha_b)
+        h = conv1d(x_snaked, w7p, C, 7, bias=b7, dil=dil, pad=3 * dil, alpha_out=alpha_b, tvalid=tvalid)
     else:
-        h = conv1d(x, w7p, C, 7, bias=b7, dil=dil, pad=3 * dil, alpha_in=alpha_a, alpha_out=alpha_b)
-    return conv1d(h, w1p, C, 1, bias=b1, residual=x, alpha_out=alpha_next, alpha_dual=alpha_dual)
+        h = conv1d(x, w7p, C, 7, bias=b7, dil=dil, pad=3 * dil, alpha_in=alpha_a, alpha_out=alpha_b, tvalid=tvalid)
+    return conv1d(h, w1p, C, 1, bias=b1, residual=x, alpha_out=alpha_next, alpha_dual=alpha_dual, tvalid=tvalid)
 
 
-def conv_transpose1d(x, wp, cout, stride, pad, bias=None, alpha_in=None, alpha_out=None, alpha_dual=None):
+def conv_transpose1d(x, wp, cout, stride, pad, bias=None, alpha_in=None, alpha_out=None, alpha_dual=None, tout_rows=0,
+                     tvalid=0):
+    """tout_rows / tvalid: zero-padded rows (include/mvq.h): row length of the output and its true length."""
     x = _dev(x, "x")
     B, cin, tin = x.shape
-    tout = (tin - 1) * stride - 2 * pad + 2 * stride
+    tout = int(tout_rows) if tout_rows else (tin - 1) * stride - 2 * pad + 2 * stride
     out = torch.empty(B, cout, max(tout, 0), device=x.device, dtype=torch.float32)
     y2 = torch.empty_like(out) if alpha_dual is not None else None
-    check(_lib.lib().mvq_conv_transpose1d_dual_f32(x.data_ptr(), wp.data_ptr(), _p(bias), _p(alpha_in), _p(alpha_out),
-                                                   out.data_ptr(), _p(y2), _p(alpha_dual), B, cin, tin, cout, stride,
-                                                   pad, _stream()), "mvq_conv_transpose1d_f32")
+    check(_lib.lib().mvq_conv_transpose1d_padded_f32(x.data_ptr(), wp.data_ptr(), _p(bias), _p(alpha_in), _p(alpha_out),
+                                                     out.data_ptr(), _p(y2), _p(alpha_dual), B, cin, tin, cout, stride,
+                                                     pad, int(tout_rows), int(tvalid), _stream()), "mvq_conv_transpose1d_f32")
     return out if alpha_dual is None else (out, y2)
 
 
