@@ -316,3 +316,51 @@ def test_align_by_xcorr_bit_exact(orc, dev):
         assert np.array_equal(corr.cpu().numpy(), want_corr)
         r_a, e_a, s = mvq.align_by_xcorr(_t(ref, dev), _t(est, dev), 200)
         assert s == want_s and np.array_equal(r_a.cpu().numpy(), g[f"{name}.ref_a"]) and np.array_equal(e_a.cpu().numpy(), g[f"{name}.est_a"])
+
+
+@pytest.mark.parametrize("B,C,T,ks,dil", [(5, 384, 2999, 7, 3), (5, 384, 2999, 1, 1), (2, 1024, 75, 7, 1), (6, 192, 1001, 7, 9)])
+def test_zero_padded_rows_conv(B, C, T, ks, dil, orc, dev):
+    """mvq_conv1d_padded_f32: rows rounded up to a multiple of 4 with a zero tail give bit-identical true columns and a zero
+    tail again (so the next layer can consume them), with residual, Snake and dual output in the epilogue."""
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    r = _rng(C + T + ks)
+    Tp = (T + 3) // 4 * 4
+    pad = (ks - 1) * dil // 2
+    x = r.standard_normal((B, C, T)).astype(np.float32)
+    w = (r.standard_normal((C, C, ks)) / math.sqrt(C * ks)).astype(np.float32)
+    b = (0.1 * r.standard_normal(C)).astype(np.float32)
+    res = r.standard_normal((B, C, T)).astype(np.float32)
+    ao = r.uniform(0.5, 1.5, C).astype(np.float32); a2 = r.uniform(0.5, 1.5, C).astype(np.float32)
+    want = orc.conv1d(x, w, b, 1, dil, pad, None, res, None, False)
+    want_s = orc.snake(want, a2)
+    xp = np.zeros((B, C, Tp), np.float32); xp[..., :T] = x
+    rp = np.zeros((B, C, Tp), np.float32); rp[..., :T] = res
+    y, y2 = ops.conv1d(_t(xp, dev), ops.pack_conv1d(_t(w, dev)), C, ks, bias=_t(b, dev), dil=dil, pad=pad,
+                       residual=_t(rp, dev), alpha_dual=_t(a2, dev), tvalid=T)
+    y, y2 = y.cpu().numpy(), y2.cpu().numpy()
+    assert y.shape == (B, C, Tp)
+    assert np.array_equal(y[..., :T], want) and np.array_equal(y2[..., :T], want_s)
+    assert not y[..., T:].any() and not y2[..., T:].any()
+
+
+@pytest.mark.parametrize("B,Cin,Tin,Cout,s", [(6, 768, 600, 384, 5), (24, 1536, 75, 768, 8), (8, 384, 2999, 192, 4)])
+def test_zero_padded_rows_conv_transpose(B, Cin, Tin, Cout, s, orc, dev):
+    """mvq_conv_transpose1d_padded_f32: (a) output rows padded up to a multiple of 4 with a zeroed tail, (b) input rows that
+    carry a zero tail with only the true outputs produced."""
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    r = _rng(Cin + Tin + s)
+    pad = math.ceil(s / 2)
+    x = r.standard_normal((B, Cin, Tin)).astype(np.float32)
+    w = (r.standard_normal((Cin, Cout, 2 * s)) / math.sqrt(Cin * 2)).astype(np.float32)
+    b = (0.1 * r.standard_normal(Cout)).astype(np.float32)
+    want = orc.conv_transpose1d(x, w, b, s, pad, None, None)
+    Tn = want.shape[-1]
+    wp = ops.pack_conv_transpose1d(_t(w, dev), s)
+    Tp = (Tn + 3) // 4 * 4
+    if Tp != Tn and Tp <= Tn + pad:                                          # (a)
+        y = ops.conv_transpose1d(_t(x, dev), wp, Cout, s, pad, bias=_t(b, dev), tout_rows=Tp, tvalid=Tn).cpu().numpy()
+        assert y.shape[-1] == Tp and np.array_equal(y[..., :Tn], want) and not y[..., Tn:].any()
+    Tip = (Tin + 3) // 4 * 4 if Tin % 4 else Tin + 4                          # (b) input with a zero tail
+    xp = np.zeros((B, Cin, Tip), np.float32); xp[..., :Tin] = x
+    y = ops.conv_transpose1d(_t(xp, dev), wp, Cout, s, pad, bias=_t(b, dev), tout_rows=Tn).cpu().numpy()
+    assert y.shape[-1] == Tn and np.array_equal(y, want)
