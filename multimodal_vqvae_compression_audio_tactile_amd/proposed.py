@@ -259,10 +259,13 @@ class _ProposedBase(nn.Module):
 class ProposedEval(_ProposedBase):
     """Evaluation/dac_vcpwq_proposed6_latency.py:437-487."""
 
+    TWO_STREAM_MAX_BATCH = 64     # up to this many segments the two encoder branches run on two HIP streams (measured:
+                                  # 8 % at B = 1-8, 5 % at 32, 1 % at 48-64, nothing from 128 on; tools/two_stream_probe.py)
+
     def _encode_branches(self, a_1T, t_1T):
         """qa = A_QUANT(A_ENC(a)) and zt = T_ENC(t) are independent.  In the latency regime (few segments: every
         launch underfills the 256 CUs) the audio branch runs on a second HIP stream beside the tactile branch."""
-        if a_1T.shape[0] > 4 or not a_1T.is_cuda:
+        if a_1T.shape[0] > self.TWO_STREAM_MAX_BATCH or not a_1T.is_cuda:
             za = self.A_ENC(a_1T)
             qa, *_ = self.A_QUANT(za)
             return qa, self.T_ENC(t_1T)
