@@ -221,6 +221,30 @@ class _ProposedBase(nn.Module):
                 ops.unfold_into_(r_tokens, s, rD, B)
         return z_run, r_tokens
 
+    TWO_STREAM_MAX_BATCH = 64     # up to this many segments the two encoder branches run on two HIP streams (measured:
+                                  # 8 % at B = 1-8, 5 % at 32, 1 % at 48-64, nothing from 128 on; tools/two_stream_probe.py)
+
+    def _encode_branches(self, a_1T, t_1T):
+        """qa = A_QUANT(A_ENC(a)) and zt = T_ENC(t) are independent.  In the latency regime (few segments: every
+        launch underfills the 256 CUs) the audio branch runs on a second HIP stream beside the tactile branch."""
+        if a_1T.shape[0] > self.TWO_STREAM_MAX_BATCH or not a_1T.is_cuda:
+            za = self.A_ENC(a_1T)
+            qa, *_ = self.A_QUANT(za)
+            return qa, self.T_ENC(t_1T)
+        cur = torch.cuda.current_stream()
+        side = getattr(self, "_side_stream", None)
+        if side is None or side.device != a_1T.device:
+            side = torch.cuda.Stream(device=a_1T.device)
+            self._side_stream = side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            za = self.A_ENC(a_1T)
+            qa, *_ = self.A_QUANT(za)
+        zt = self.T_ENC(t_1T)
+        cur.wait_stream(side)
+        for x in (za, qa):
+            x.record_stream(cur)
+        return qa, zt
 
     def _ar_latents_train(self, qa, zt):
         """The same loop recorded for autograd: z_hat of chunk c feeds column 0 of chunk c+1's zt_prev WITH gradient
@@ -259,31 +283,6 @@ class _ProposedBase(nn.Module):
 class ProposedEval(_ProposedBase):
     """Evaluation/dac_vcpwq_proposed6_latency.py:437-487."""
 
-    TWO_STREAM_MAX_BATCH = 64     # up to this many segments the two encoder branches run on two HIP streams (measured:
-                                  # 8 % at B = 1-8, 5 % at 32, 1 % at 48-64, nothing from 128 on; tools/two_stream_probe.py)
-
-    def _encode_branches(self, a_1T, t_1T):
-        """qa = A_QUANT(A_ENC(a)) and zt = T_ENC(t) are independent.  In the latency regime (few segments: every
-        launch underfills the 256 CUs) the audio branch runs on a second HIP stream beside the tactile branch."""
-        if a_1T.shape[0] > self.TWO_STREAM_MAX_BATCH or not a_1T.is_cuda:
-            za = self.A_ENC(a_1T)
-            qa, *_ = self.A_QUANT(za)
-            return qa, self.T_ENC(t_1T)
-        cur = torch.cuda.current_stream()
-        side = getattr(self, "_side_stream", None)
-        if side is None or side.device != a_1T.device:
-            side = torch.cuda.Stream(device=a_1T.device)
-            self._side_stream = side
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            za = self.A_ENC(a_1T)
-            qa, *_ = self.A_QUANT(za)
-        zt = self.T_ENC(t_1T)
-        cur.wait_stream(side)
-        for x in (za, qa):
-            x.record_stream(cur)
-        return qa, zt
-
     @torch.no_grad()
     def encode_latents(self, a_1T, t_1T, books_use=None):
         qa, zt = self._encode_branches(a_1T, t_1T)
@@ -314,9 +313,7 @@ class AllPredAR(_ProposedBase):
     def forward_step(self, a_1T, tc_1T):
         Tw = tc_1T.shape[-1]
         with torch.no_grad():                                                  # frozen backbones: no graph
-            za = self.A_ENC(a_1T)
-            qa, *_ = self.A_QUANT(za)
-            zt = self.T_ENC(tc_1T)
+            qa, zt = self._encode_branches(a_1T, tc_1T)
         if torch.is_grad_enabled() and zt.numel() and any(p.requires_grad for p in self.parameters()):
             z_run, r_tokens = self._ar_latents_train(qa, zt)
             y_hat = self.T_DEC(z_run)                                          # _DecoderInputGrad: HIP backward w.r.t. z
