@@ -34,6 +34,7 @@ extern "C" {
 
 #define MVQ_ACT_NONE 0
 #define MVQ_ACT_TANH 1
+#define MVQ_ACT_GELU 2   /* exact-erf GELU (nn.GELU() of CrossPredictor.ffn); MFMA-tiled, non-transposed shapes only */
 
 int mvq_abi_version(void);
 const char* mvq_last_error(void);
@@ -161,6 +162,11 @@ int mvq_dac_rvq_items_f32(const float* z, const float* in_w, const float* in_b, 
 int mvq_layernorm_c_f32(const float* x, const float* pe, const float* gamma, const float* beta, float* y,
                         int batch, int c, int t, size_t stride_b, size_t stride_c,
                         float eps, int do_tanh, float post_scale, void* stream);
+/* The same on x - sub (element-wise, same addressing): the AR residual r = zt - z_pred followed by tanh(TokenNorm(r))*scale
+ * (Training/compare_dacvsproposal_5.py:312-315) in one launch; sub may be NULL. */
+int mvq_layernorm_c_sub_f32(const float* x, const float* sub, const float* pe, const float* gamma, const float* beta, float* y,
+                            int batch, int c, int t, size_t stride_b, size_t stride_c,
+                            float eps, int do_tanh, float post_scale, void* stream);
 
 /* softmax(Q K^T / sqrt(dh)) V per head (Training/compare_dacvsproposal_5.py:239-242).  Q, ctx: (b,c,i) at
  * b*q_stride_b + c*q_stride_c + i ; K, V: (b,c,j) at b*k_stride_b + c*k_stride_c + j (0,0 = contiguous).

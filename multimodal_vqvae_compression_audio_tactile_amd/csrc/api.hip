@@ -151,7 +151,7 @@ int mvq_conv1d_padded_f32(const float* x, const float* wp, const float* bias, co
 {
     if (batch < 0 || cin <= 0 || cout <= 0 || tin < 0 || ks <= 0 || stride <= 0 || dil <= 0 || pad < 0)
         return fail(MVQ_EINVAL, "conv1d: bad shape B=%d Cin=%d Tin=%d Cout=%d ks=%d s=%d d=%d p=%d", batch, cin, tin, cout, ks, stride, dil, pad);
-    if (act != MVQ_ACT_NONE && act != MVQ_ACT_TANH) return fail(MVQ_EINVAL, "conv1d: bad act %d", act);
+    if (act != MVQ_ACT_NONE && act != MVQ_ACT_TANH && act != MVQ_ACT_GELU) return fail(MVQ_EINVAL, "conv1d: bad act %d", act);
     const int tout = conv_out_len(tin, ks, stride, dil, pad);
     if (batch == 0 || tout == 0) return MVQ_OK;
     if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv1d: null tensor");
@@ -166,7 +166,8 @@ int mvq_conv1d_padded_f32(const float* x, const float* wp, const float* bias, co
     a.tvalid = (tvalid == tout) ? 0 : tvalid;
 
     hipError_t e = dispatch_conv1d(a, ks, stride, dil, S(stream));
-    if (e == hipErrorInvalidValue && a.tvalid) return fail(MVQ_EUNSUPPORTED, "conv1d: zero-padded rows need an MFMA-tiled shape");
+    if (e == hipErrorInvalidValue && (a.tvalid || act == MVQ_ACT_GELU))
+        return fail(MVQ_EUNSUPPORTED, "conv1d: zero-padded rows / the GELU epilogue need an MFMA-tiled shape");
     if (e == hipErrorInvalidValue) {
         (void)hipGetLastError();
         mvq::DirectConvArgs d{x, wp, bias, alpha_in, residual, alpha_out, y, batch, cin, tin, cout, tout, ks, stride, dil, pad, mpad, act, y2, alpha2, nullptr, nullptr};
@@ -358,11 +359,18 @@ int mvq_layernorm_c_f32(const float* x, const float* pe, const float* gamma, con
                         int batch, int c, int t, size_t stride_b, size_t stride_c,
                         float eps, int do_tanh, float post_scale, void* stream)
 {
+    return mvq_layernorm_c_sub_f32(x, nullptr, pe, gamma, beta, y, batch, c, t, stride_b, stride_c, eps, do_tanh, post_scale, stream);
+}
+
+int mvq_layernorm_c_sub_f32(const float* x, const float* sub, const float* pe, const float* gamma, const float* beta, float* y,
+                            int batch, int c, int t, size_t stride_b, size_t stride_c,
+                            float eps, int do_tanh, float post_scale, void* stream)
+{
     if (c <= 0 || batch < 0 || t < 0) return fail(MVQ_EINVAL, "layernorm_c: bad shape");
     if (batch == 0 || t == 0) return MVQ_OK;                      /* empty chunk (Tk == 0 at a file end) */
     if (!x || !gamma || !beta || !y) return fail(MVQ_EINVAL, "layernorm_c: null tensor");
     if (stride_b == 0 && stride_c == 0) { stride_b = (size_t)c * t; stride_c = (size_t)t; }
-    hipError_t e = mvq::launch_layernorm_c(x, pe, gamma, beta, y, batch, c, t, stride_b, stride_c, eps, do_tanh, post_scale, S(stream));
+    hipError_t e = mvq::launch_layernorm_c(x, pe, gamma, beta, y, batch, c, t, stride_b, stride_c, eps, do_tanh, post_scale, sub, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "layernorm_c");
 }
 

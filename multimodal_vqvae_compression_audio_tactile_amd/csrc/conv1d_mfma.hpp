@@ -391,6 +391,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     const bool has_res = (UPS == 0) && a.residual != nullptr;
     const bool snake_out = a.alpha_out != nullptr;
     const bool do_tanh = a.act == 1;
+    const bool do_gelu = a.act == 2;
     const bool direct = (UPS != 0) && (C::BM % (UPS ? UPS : 1) != 0);
     if (direct) {
 #pragma unroll
@@ -482,6 +483,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                         v.z = det_snake(v.z, al, inv); v.w = det_snake(v.w, al, inv);
                     }
                     if (do_tanh) { v.x = det_tanh(v.x); v.y = det_tanh(v.y); v.z = det_tanh(v.z); v.w = det_tanh(v.w); }
+                    if (do_gelu) { v.x = det_gelu(v.x); v.y = det_gelu(v.y); v.z = det_gelu(v.z); v.w = det_gelu(v.w); }
                     if (nz > 0) { v.w = 0.0f; if (nz > 1) v.z = 0.0f; if (nz > 2) v.y = 0.0f; if (nz > 3) v.x = 0.0f; }
                     *reinterpret_cast<f32x4*>(a.y + off) = v;
                 }
@@ -502,6 +504,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     if (a.y2) { const float a2 = a.alpha2[m]; a.y2[off] = tail ? 0.0f : det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
                     if (snake_out) { const float al = a.alpha_out[m]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
                     if (do_tanh) v = det_tanh(v);
+                    if (do_gelu) v = det_gelu(v);
                     a.y[off] = tail ? 0.0f : v;
                 }
             }

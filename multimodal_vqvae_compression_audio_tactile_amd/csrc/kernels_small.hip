@@ -329,7 +329,7 @@ constexpr int LN_TOK = 32;
 __global__ __launch_bounds__(256) void layernorm_c_tile_kernel(
     const float* __restrict__ x, const float* __restrict__ pe, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ y, int B, int C, int T, size_t sb, size_t sc,
-    float eps, int do_tanh, float post_scale)
+    float eps, int do_tanh, float post_scale, const float* __restrict__ sub)
 {
     extern __shared__ __attribute__((aligned(16))) float tile[];      // [C][LN_TOK] | mean[LN_TOK] | rstd[LN_TOK]
     float* mean_s = tile + (size_t)C * LN_TOK;
@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256) void layernorm_c_tile_kernel(
     const bool live = n < B * T;
     const int b = live ? n / T : 0, t = live ? n - b * T : 0;
     const float* xb = x + (size_t)b * sb + t;
+    const float* sbp = sub ? sub + (size_t)b * sb + t : nullptr;       // x - sub (the AR residual r = zt - z_pred), same layout
     const float* per = pe ? pe + (size_t)t * C : nullptr;
     constexpr int CG = 256 / LN_TOK;                                   // channel groups (8)
     for (int c0 = cg; c0 < C; c0 += CG * 8) {                          // 8 loads in flight per thread
@@ -349,6 +350,10 @@ __global__ __launch_bounds__(256) void layernorm_c_tile_kernel(
         for (int u = 0; u < 8; ++u) {
             const int c = c0 + u * CG;
             v[u] = (live && c < C) ? xb[(size_t)c * sc] : 0.0f;
+        }
+        if (sbp) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int c = c0 + u * CG; if (live && c < C) v[u] = v[u] - sbp[(size_t)c * sc]; }
         }
         if (per) {
 #pragma unroll
@@ -398,16 +403,18 @@ __global__ __launch_bounds__(256) void layernorm_c_tile_kernel(
 __global__ void layernorm_c_kernel(const float* __restrict__ x, const float* __restrict__ pe,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ y, int B, int C, int T, size_t sb, size_t sc,
-                                   float eps, int do_tanh, float post_scale)
+                                   float eps, int do_tanh, float post_scale, const float* __restrict__ sub)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= B * T) return;
     const int b = n / T, t = n - b * T;
     const float* xb = x + (size_t)b * sb + t;
+    const float* sbp = sub ? sub + (size_t)b * sb + t : nullptr;
     const float* per = pe ? pe + (size_t)t * C : nullptr;
     float s = 0.0f;
     for (int c = 0; c < C; ++c) {
         float v = xb[(size_t)c * sc];
+        if (sbp) v = v - sbp[(size_t)c * sc];
         if (per) v = v + per[c];
         s = s + v;
     }
@@ -415,6 +422,7 @@ __global__ void layernorm_c_kernel(const float* __restrict__ x, const float* __r
     float var = 0.0f;
     for (int c = 0; c < C; ++c) {
         float v = xb[(size_t)c * sc];
+        if (sbp) v = v - sbp[(size_t)c * sc];
         if (per) v = v + per[c];
         const float d = v - mean;
         var = dfma(d, d, var);
@@ -423,6 +431,7 @@ __global__ void layernorm_c_kernel(const float* __restrict__ x, const float* __r
     float* yb = y + (size_t)b * sb + t;
     for (int c = 0; c < C; ++c) {
         float v = xb[(size_t)c * sc];
+        if (sbp) v = v - sbp[(size_t)c * sc];
         if (per) v = v + per[c];
         float o = dfma((v - mean) * rstd, gamma[c], beta[c]);
         if (do_tanh) o = det_tanh(o);
@@ -433,7 +442,7 @@ __global__ void layernorm_c_kernel(const float* __restrict__ x, const float* __r
 
 hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamma, const float* beta, float* y,
                               int B, int C, int T, size_t sb, size_t sc, float eps, int do_tanh, float post_scale,
-                              hipStream_t s)
+                              const float* sub, hipStream_t s)
 {
     const int n = B * T;
     if (n == 0) return hipSuccess;
@@ -447,10 +456,10 @@ hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamm
             attr = true;
         }
         hipLaunchKernelGGL(layernorm_c_tile_kernel, dim3((n + LN_TOK - 1) / LN_TOK), dim3(256), lds, s,
-                           x, pe, gamma, beta, y, B, C, T, sb, sc, eps, do_tanh, post_scale);
+                           x, pe, gamma, beta, y, B, C, T, sb, sc, eps, do_tanh, post_scale, sub);
     } else {
         hipLaunchKernelGGL(layernorm_c_kernel, dim3((n + 63) / 64), dim3(64), 0, s, x, pe, gamma, beta, y, B, C, T, sb, sc,
-                           eps, do_tanh, post_scale);
+                           eps, do_tanh, post_scale, sub);
     }
     return hipGetLastError();
 }

@@ -21,7 +21,7 @@ hipError_t launch_conv1d_direct(const DirectConvArgs& a, hipStream_t s);
 hipError_t launch_convtr_direct(const DirectConvArgs& a, hipStream_t s);
 hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamma, const float* beta, float* y,
                               int B, int C, int T, size_t sb, size_t sc, float eps, int do_tanh, float post_scale,
-                              hipStream_t s);
+                              const float* sub, hipStream_t s);
 hipError_t launch_attention(const float* q, const float* k, const float* v, float* ctx,
                             int B, int H, int dh, int Tq, int Tk, size_t qsb, size_t qsc, size_t ksb, size_t ksc,
                             hipStream_t s);

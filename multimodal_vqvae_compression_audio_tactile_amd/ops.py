@@ -79,7 +79,7 @@ def pack_conv_transpose1d(w: torch.Tensor, stride: int) -> torch.Tensor:
 
 
 def conv1d(x, wp, cout, ks, bias=None, stride=1, dil=1, pad=0, alpha_in=None, residual=None, alpha_out=None,
-           tanh=False, out=None, alpha_dual=None, tvalid=0):
+           tanh=False, out=None, alpha_dual=None, tvalid=0, gelu=False):
     """alpha_dual: also return snake(y_raw, alpha_dual) (the next ResidualUnit's Snake, hoisted): -> (y, y2).
     tvalid: rows are zero-padded beyond column tvalid (see include/mvq.h "Zero-padded rows"); 0 = plain tensors."""
     x = _dev(x, "x")
@@ -94,7 +94,7 @@ def conv1d(x, wp, cout, ks, bias=None, stride=1, dil=1, pad=0, alpha_in=None, re
             raise MvqError(f"conv1d: residual shape {tuple(residual.shape)} != {(B, cout, tout)}")
     check(_lib.lib().mvq_conv1d_padded_f32(x.data_ptr(), wp.data_ptr(), _p(bias), _p(alpha_in), _p(residual),
                                            _p(alpha_out), out.data_ptr(), _p(y2), _p(alpha_dual), B, cin, tin, cout, ks,
-                                           stride, dil, pad, 1 if tanh else 0, int(tvalid), _stream()), "mvq_conv1d_f32")
+                                           stride, dil, pad, 1 if tanh else (2 if gelu else 0), int(tvalid), _stream()), "mvq_conv1d_f32")
     return out if alpha_dual is None else (out, y2)
 
 
@@ -195,9 +195,14 @@ def dac_rvq(z, in_w, in_b, codebook, out_w, out_b, n_q, nq_item=None):
     return zq, codes.long(), lat
 
 
-def layernorm_c(x, gamma, beta, pe=None, eps=1e-5, do_tanh=False, post_scale=1.0, folded_batch=None):
-    """LayerNorm over channels of x[B,C,T]; with ``folded_batch=B`` x is the token-folded [1,C,B*T] layout."""
+def layernorm_c(x, gamma, beta, pe=None, eps=1e-5, do_tanh=False, post_scale=1.0, folded_batch=None, sub=None):
+    """LayerNorm over channels of x[B,C,T] (of x - sub when ``sub`` is given); with ``folded_batch=B`` x is the
+    token-folded [1,C,B*T] layout."""
     x = _dev(x, "x")
+    if sub is not None:
+        sub = _dev(sub, "sub")
+        if sub.shape != x.shape:
+            raise MvqError("layernorm_c: sub must have the shape of x")
     B, C, T = x.shape
     sb = sc = 0
     if folded_batch is not None:
@@ -208,8 +213,8 @@ def layernorm_c(x, gamma, beta, pe=None, eps=1e-5, do_tanh=False, post_scale=1.0
     y = torch.empty_like(x)
     if pe is not None and (pe.shape[0] < T or pe.shape[1] != C):
         raise MvqError(f"layernorm_c: pe table {tuple(pe.shape)} too small for T={T}, C={C}")
-    check(_lib.lib().mvq_layernorm_c_f32(x.data_ptr(), _p(pe), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                         B, C, T, sb, sc, float(eps), int(do_tanh), float(post_scale), _stream()),
+    check(_lib.lib().mvq_layernorm_c_sub_f32(x.data_ptr(), _p(sub), _p(pe), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                             B, C, T, sb, sc, float(eps), int(do_tanh), float(post_scale), _stream()),
           "mvq_layernorm_c_f32")
     return y
 
@@ -226,6 +231,20 @@ def attention(q, k, v, heads, folded_batch=None):
     ctx = torch.empty_like(q)
     check(_lib.lib().mvq_attention_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), ctx.data_ptr(), B, heads, C // heads,
                                        Tq, Tk, *strides, _stream()), "mvq_attention_f32")
+    return ctx
+
+
+def attention_kv_slice(q, k_all, v_all, heads, folded_batch, s, tk):
+    """Attention of token-folded q[1,C,B*Tq] against columns [s, s+tk) of token-folded K/V over the WHOLE sequence
+    (k_all, v_all: [1, C, B*Ta], column b*Ta + t): the kernel takes strides, nothing is copied."""
+    q = _dev(q, "q"); k_all = _dev(k_all, "k"); v_all = _dev(v_all, "v")
+    B = folded_batch
+    C, Tq, Ta = q.shape[1], q.shape[2] // B, k_all.shape[2] // B
+    if s < 0 or tk < 0 or s + tk > Ta:
+        raise MvqError("attention_kv_slice: slice outside the key/value sequence")
+    ctx = torch.empty_like(q)
+    check(_lib.lib().mvq_attention_f32(q.data_ptr(), k_all.data_ptr() + 4 * s, v_all.data_ptr() + 4 * s, ctx.data_ptr(),
+                                       B, heads, C // heads, Tq, tk, Tq, B * Tq, Ta, B * Ta, _stream()), "mvq_attention_f32")
     return ctx
 
 

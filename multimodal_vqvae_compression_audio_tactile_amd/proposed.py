@@ -65,10 +65,12 @@ class _PackedLinear:
         w = self.mod.weight
         return self.cache.get((w,), lambda: ops.pack_conv1d(w.detach().reshape(w.shape[0], w.shape[1], 1)))
 
-    def __call__(self, x, residual=None):
+    def __call__(self, x, residual=None, gelu=False):
         w = self.mod.weight
         b = self.mod.bias.detach() if getattr(self.mod, "bias", None) is not None else None
-        return ops.conv1d(x, self.wp(), w.shape[0], 1, bias=b, residual=residual)
+        if gelu and (w.shape[1] % 32 or w.shape[0] < 64):                  # GELU epilogue exists on the MFMA tiles only
+            return ops.gelu(ops.conv1d(x, self.wp(), w.shape[0], 1, bias=b, residual=residual))
+        return ops.conv1d(x, self.wp(), w.shape[0], 1, bias=b, residual=residual, gelu=gelu)
 
 
 class CrossPredictor(nn.Module):
@@ -86,21 +88,39 @@ class CrossPredictor(nn.Module):
                                                       ("o", self.out), ("f1", self.ffn[1]), ("f3", self.ffn[3]))}
 
     @torch.no_grad()
-    def run(self, zt_prev, za, folded_batch=None):
-        """zt_prev[B,C,Tq], za[B,C,Tk] (or both token-folded [1,C,B*T] with folded_batch=B) -> same layout."""
+    def keys_values(self, qa_folded, folded_batch, chunk):
+        """K and V of EVERY chunk in one pass: the audio side of the predictor does not depend on the AR state, so the
+        per-chunk LayerNorm + two GEMMs (15 launches per segment batch) collapse into 3 over all B*Ta tokens.  PosEnc1D
+        restarts at each chunk (the reference applies it per chunk, Training/...5.py:305-309): row t of the table is
+        pe[t mod chunk]."""
+        Ta = qa_folded.shape[2] // folded_batch
+        key = (Ta, chunk, str(qa_folded.device))
+        if getattr(self, "_pe_tiled", (None,))[0] != key:
+            reps = (Ta + chunk - 1) // chunk
+            self._pe_tiled = (key, self.pos.pe[:chunk].repeat(reps, 1)[:Ta].contiguous())
+        kv = ops.layernorm_c(qa_folded, self.ln_kv.weight.detach(), self.ln_kv.bias.detach(), pe=self._pe_tiled[1],
+                             eps=self.ln_kv.eps, folded_batch=folded_batch)
+        return self._lin["k"](kv), self._lin["v"](kv)
+
+    @torch.no_grad()
+    def run(self, zt_prev, za, folded_batch=None, kv_all=None, kv_slice=None):
+        """zt_prev[B,C,Tq], za[B,C,Tk] (or both token-folded [1,C,B*T] with folded_batch=B) -> same layout.
+        kv_all = keys_values(...) with kv_slice = (s, tk): attend to columns [s, s+tk) of the precomputed K / V."""
         fb = folded_batch
         pe = self.pos.pe
         q = ops.layernorm_c(zt_prev, self.ln_q.weight.detach(), self.ln_q.bias.detach(), pe=pe, eps=self.ln_q.eps,
                             folded_batch=fb)
-        kv = ops.layernorm_c(za, self.ln_kv.weight.detach(), self.ln_kv.bias.detach(), pe=pe, eps=self.ln_kv.eps,
-                             folded_batch=fb)
         L = self._lin
-        Q, K, V = L["q"](q), L["k"](kv), L["v"](kv)
-        ctx = ops.attention(Q, K, V, self.h, folded_batch=fb)
+        if kv_all is not None:
+            ctx = ops.attention_kv_slice(L["q"](q), kv_all[0], kv_all[1], self.h, fb, kv_slice[0], kv_slice[1])
+        else:
+            kv = ops.layernorm_c(za, self.ln_kv.weight.detach(), self.ln_kv.bias.detach(), pe=pe, eps=self.ln_kv.eps,
+                                 folded_batch=fb)
+            ctx = ops.attention(L["q"](q), L["k"](kv), L["v"](kv), self.h, folded_batch=fb)
         y1 = L["o"](ctx, residual=q)                                        # out(ctx) + q
         hdn = ops.layernorm_c(y1, self.ffn[0].weight.detach(), self.ffn[0].bias.detach(), eps=self.ffn[0].eps,
                               folded_batch=fb)
-        hdn = ops.gelu(L["f1"](hdn))
+        hdn = L["f1"](hdn, gelu=True)                                       # nn.GELU() in the GEMM epilogue
         return L["f3"](hdn, residual=y1)                                    # ffn(y) + y
 
     def run_train(self, zt_prev, za, folded_batch):
@@ -197,22 +217,28 @@ class _ProposedBase(nn.Module):
             return z_run, r_tokens
         scale = self._scale_value()
         ln = self.tokennorm.ln
+        kv_all = None
+        if not tactile_only:
+            Ta = min(qa.shape[-1], Tlat)                                      # audio may be shorter (whole-file mode)
+            if Ta > 0:                                                        # K, V of all chunks up front (3 launches)
+                kv_all = self.predict.keys_values(ops.fold_time_slice(qa, 0, Ta), B, AR_CHUNK_TOK)
         for s in range(0, Tlat, AR_CHUNK_TOK):
             e = min(Tlat, s + AR_CHUNK_TOK)
             n = e - s
             zt_c = ops.fold_time_slice(zt, s, e)                             # [1,C,B*n]
             if tactile_only:
-                z_pred, r = None, zt_c
+                z_pred = None
             else:
                 zt_prev = torch.zeros(1, C, B * n, device=zt.device, dtype=torch.float32)
                 if s > 0:                                                     # column 0 <- z_run[..., s-1]
                     ops.fold_column_into_(zt_prev, 0, z_run, s - 1, B)
-                ka = min(qa.shape[-1], e) - min(qa.shape[-1], s)              # audio may be shorter (whole-file mode)
-                qa_c = ops.fold_time_slice(qa, s, s + ka) if ka > 0 else torch.zeros(1, C, 0, device=zt.device)
-                z_pred = self.predict.run(zt_prev, qa_c, folded_batch=B)
-                r = ops.sub(zt_c, z_pred)
-            rN = ops.layernorm_c(r, ln.weight.detach(), ln.bias.detach(), eps=ln.eps, do_tanh=True, post_scale=scale,
-                                 folded_batch=B)
+                ka = min(qa.shape[-1], e) - min(qa.shape[-1], s)
+                if ka > 0:
+                    z_pred = self.predict.run(zt_prev, None, folded_batch=B, kv_all=kv_all, kv_slice=(s, ka))
+                else:
+                    z_pred = self.predict.run(zt_prev, torch.zeros(1, C, 0, device=zt.device), folded_batch=B)
+            rN = ops.layernorm_c(zt_c, ln.weight.detach(), ln.bias.detach(), eps=ln.eps, do_tanh=True, post_scale=scale,
+                                 folded_batch=B, sub=z_pred)                  # tanh(TokenNorm(zt - z_pred)) * scale
             rD = self._pd(rN)                                                 # [1,96,B*n]
             qD = self.vq(rD, n_books_use=books_use)
             z_hat = self._pu(qD, residual=z_pred)
