@@ -198,15 +198,32 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
+    dist, grp, backend_used = None, None, None
     if world > 1:
+        # The rendezvous and the agreement on the backend go over gloo (host only: cannot fail for GPU reasons); RCCL is
+        # then brought up as a group of its own and PROVEN with one all-reduce.  Every rank reports over gloo whether that
+        # worked; unless all did, the whole job keeps gloo for its barriers / timing reduction instead of dying or hanging
+        # half-initialised.  (Inference has no data-path collective at all; training all-reduces 34 MB of gradients.)
+        import datetime
         import torch.distributed as dist_mod
         dist = dist_mod
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+        backend_used = "gloo"
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
-    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
+            ok = 0
+            try:
+                g = dist.new_group(backend="nccl")
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe, group=g)
+                torch.cuda.synchronize()
+                ok = int(round(float(probe.item())) == world)
+            except Exception as ex:                                      # e.g. two ranks on one device in a rehearsal
+                print(f"[bench rank {rank}] RCCL group unavailable ({type(ex).__name__}); using gloo for control", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                grp, backend_used = g, "nccl"
+    red_dev = dev if backend_used == "nccl" else torch.device("cpu")
 
     import multimodal_vqvae_compression_audio_tactile_amd as mvq
     from multimodal_vqvae_compression_audio_tactile_amd import ops, synth
@@ -234,7 +251,7 @@ def main():
                 opt.zero_grad(set_to_none=True)
                 total.backward()
             if dist:
-                mdist.allreduce_grads(params, B)
+                mdist.allreduce_grads(params, B, group=grp)
             if args.torch_optim:
                 torch.nn.utils.clip_grad_norm_(params, 3.0)
                 opt.step()
@@ -242,7 +259,7 @@ def main():
                 _, coef = mvq.optim.clip_coef(params, 3.0)      # clip_grad_norm_(params, 3.0) fused into the update
                 opt.step(clip_coef=coef)
             if dist:
-                mdist.ema_step_all_ranks(net.vq, out["r_tokens"])
+                mdist.ema_step_all_ranks(net.vq, out["r_tokens"], group=grp)
             else:
                 net.vq.ema_step(out["r_tokens"])
             return out["y_hat"].detach()
@@ -258,19 +275,19 @@ def main():
     if not args.no_kernel_events and not train:           # the train step has ~600 small launches: the per-launch host cost
         kev = KernelEvents(); kev.wrap(ops)               # of the event wrappers would be what gets measured
 
-    if dist: dist.barrier()
+    if dist: dist.barrier(group=grp)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y = step()
     torch.cuda.synchronize()
-    if dist: dist.barrier()
+    if dist: dist.barrier(group=grp)
     elapsed = time.perf_counter() - t0
     if kev: kev._restore()
 
     if dist:
         tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=grp)
         elapsed = float(tt.item())
 
     out_ok = bool(torch.isfinite(y).all().item()) and y.shape[0] == B
@@ -291,6 +308,7 @@ def main():
                                     "-> proj_up -> T_DEC"),
                        "segments_per_gpu_per_step": B, "segment": "1 s @ 24 kHz = 75 token-frames",
                        "sharding": f"segments sharded over {world} GPU(s), no data-path collective",
+                       "collective_backend": backend_used,
                        "weights": "seeded variance-preserving random init of the DAC-24k architecture"},
         }
         if train:

@@ -42,7 +42,6 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--books", type=int, default=8)
     ap.add_argument("--embed", type=int, default=512)
-    ap.add_argument("--backend", default="nccl")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if os.environ.get("MVQ_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
@@ -51,7 +50,7 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+        dist.init_process_group("gloo")        # the only exchange is one gather of per-rank metric lists (host objects)
 
     import multimodal_vqvae_compression_audio_tactile_amd as mvq
     from multimodal_vqvae_compression_audio_tactile_amd import dist as mdist, synth
