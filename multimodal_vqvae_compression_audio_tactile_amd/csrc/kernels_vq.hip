@@ -184,6 +184,157 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Throughput form of the same search: the scores of 32 tokens against 32 codes at a time are one 32x32 MFMA tile
+// (M = codes, N = tokens, K = the D dimensions walked two at a time), which is exactly the d-ascending fp32 fma chain of the
+// scalar kernel, so indices and sums stay bit-identical.  With M = codes every lane owns ONE token column: the running
+// arg-max over codes is a per-lane loop over its 16 accumulator rows (ascending code index, strict '>' keeps the lowest on
+// ties), then one exchange with the other lane half and one 4-way combine across the waves.
+// LDS: Es[KH][D+1] (natural code-major rows, odd pitch) | hn[KH] | resT[D][32] | qsT[D][32] | ws[4][32] | wi[4][32] | best
+// ------------------------------------------------------------------------------------------------
+typedef float rvq_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void rvq_ema_forward_mfma_kernel(
+    const float* __restrict__ z, const float* __restrict__ books, float* __restrict__ q_out,
+    int32_t* __restrict__ idx_out, int B, int D, int T, int nb, int K, int update_residual)
+{
+    constexpr int TOKS = 32;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int DP = D + 1;
+    float* Es = sm;                                   // [RVQ_KH][DP]
+    float* hn = Es + (size_t)RVQ_KH * DP;             // [RVQ_KH]
+    float* resT = hn + RVQ_KH;                        // [D][32]
+    float* qsT = resT + (size_t)D * TOKS;             // [D][32]
+    float* ws = qsT + (size_t)D * TOKS;               // [4][32]
+    int* wi = reinterpret_cast<int*>(ws + 4 * TOKS);  // [4][32]
+    float* best_s = reinterpret_cast<float*>(wi + 4 * TOKS);
+    int* best_i = reinterpret_cast<int*>(best_s + TOKS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int N = B * T;
+    const int n0 = blockIdx.x * TOKS;
+
+    for (int i = tid; i < D * TOKS; i += 256) {
+        const int tok = i % TOKS, d = i / TOKS;
+        const int n = n0 + tok;
+        float v = 0.0f;
+        if (n < N) { const int b = n / T, t = n - b * T; v = z[((size_t)b * D + d) * T + t]; }
+        resT[d * TOKS + tok] = v;
+        qsT[d * TOKS + tok] = 0.0f;
+    }
+
+    for (int bk = 0; bk < nb; ++bk) {
+        const float* emb = books + (size_t)bk * K * D;
+        for (int k0 = 0; k0 < K; k0 += RVQ_KH) {
+            const int kh = K - k0 < RVQ_KH ? K - k0 : RVQ_KH;              // multiple of 32 (checked by the launcher)
+            __syncthreads();
+            {   // stage the code rows: global row-major (coalesced 16-byte loads) -> Es[k][d], pitch D+1
+                typedef float v4 __attribute__((ext_vector_type(4)));
+                const int dv = D >> 2;
+                const int nvec = kh * dv;
+                const float* src = emb + (size_t)k0 * D;
+                for (int base = 0; base < nvec; base += 256 * 8) {
+                    v4 r[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = base + u * 256 + tid;
+                        r[u] = *reinterpret_cast<const v4*>(src + 4 * (size_t)(i < nvec ? i : nvec - 1));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = base + u * 256 + tid;
+                        if (i < nvec) {
+                            const int k = i / dv, d4 = (i - k * dv) * 4;
+                            float* dst = Es + (size_t)k * DP + d4;
+                            dst[0] = r[u].x; dst[1] = r[u].y; dst[2] = r[u].z; dst[3] = r[u].w;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int k = tid; k < kh; k += 256) {
+                float s = 0.0f;
+                for (int d = 0; d < D; ++d) { const float e = Es[(size_t)k * DP + d]; s = dfma(e, e, s); }
+                hn[k] = 0.5f * s;
+            }
+            __syncthreads();
+            // this wave's 32-code row blocks: mb = wave, wave + 4, ... (ascending, so the strict compare keeps the lowest index)
+            float bs = -__builtin_inff(); int bi = 0x7fffffff;
+            for (int mb = wave; mb * 32 < kh; mb += 4) {
+                rvq_f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                const float* ap = Es + (size_t)(mb * 32 + l31) * DP + h;
+                const float* bp = resT + h * TOKS + l31;
+                for (int sx = 0; sx < D / 2; ++sx)                           // K index = dimension, two per step
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * sx], bp[2 * sx * TOKS], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int code = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float sc = acc[r] - hn[code];
+                    if (sc > bs) { bs = sc; bi = k0 + code; }
+                }
+            }
+            {   // the other lane half holds the other 16 rows of every block for the same token
+                const float os = __shfl_xor(bs, 32);
+                const int oi = __shfl_xor(bi, 32);
+                amax_combine(bs, bi, os, oi);
+            }
+            if (h == 0) { ws[wave * TOKS + l31] = bs; wi[wave * TOKS + l31] = bi; }
+            __syncthreads();
+            if (tid < TOKS) {
+                float cs = ws[tid]; int ci = wi[tid];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) amax_combine(cs, ci, ws[w * TOKS + tid], wi[w * TOKS + tid]);
+                if (k0 != 0) amax_combine(cs, ci, best_s[tid], best_i[tid]);
+                best_s[tid] = cs; best_i[tid] = ci;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < D * TOKS; i += 256) {
+            const int d = i % D, tok = i / D;
+            int id = best_i[tok];
+            if (id < 0 || id >= K) id = 0;
+            const float q = emb[(size_t)id * D + d];
+            const float r = resT[d * TOKS + tok];
+            const float qs = qsT[d * TOKS + tok];
+            qsT[d * TOKS + tok] = (qs + (q - r)) + r;
+            if (update_residual) resT[d * TOKS + tok] = r - q;
+        }
+        if (idx_out && tid < TOKS && n0 + tid < N) {
+            int id = best_i[tid];
+            if (id < 0 || id >= K) id = 0;
+            idx_out[(size_t)bk * N + n0 + tid] = id;
+        }
+    }
+    __syncthreads();
+    if (q_out) {
+        for (int i = tid; i < D * TOKS; i += 256) {
+            const int tok = i % TOKS, d = i / TOKS;
+            const int n = n0 + tok;
+            if (n < N) { const int b = n / T, t = n - b * T; q_out[((size_t)b * D + d) * T + t] = qsT[d * TOKS + tok]; }
+        }
+    }
+}
+
+static hipError_t launch_rvq_mfma(const float* z, const float* books, float* q_out, int32_t* idx_out,
+                                  int B, int D, int T, int nb, int K, int update_residual, hipStream_t s)
+{
+    const int N = B * T;
+    const size_t lds = ((size_t)RVQ_KH * (D + 1) + RVQ_KH + 2 * (size_t)D * 32 + 8 * 32 + 2 * 32) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_ema_forward_mfma_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(rvq_ema_forward_mfma_kernel, dim3((N + 31) / 32), dim3(256), lds, s, z, books, q_out, idx_out, B, D, T,
+                       nb, K, update_residual);
+    return hipGetLastError();
+}
+
 template <int TOKS>
 static hipError_t launch_rvq_t(const float* z, const float* books, float* q_out, int32_t* idx_out,
                                int B, int D, int T, int nb, int K, int update_residual, hipStream_t s)
@@ -206,6 +357,11 @@ hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_o
 {
     const int N = B * T;
     if (N == 0) return hipSuccess;
+    // many tokens: the MFMA form (one block per 32 tokens, >= 32 blocks); few tokens: the scalar form with 8 tokens per block
+    // (more blocks, and the codebook staging rather than the arithmetic is what a short chunk waits for)
+    const size_t lds_mfma = ((size_t)RVQ_KH * (D + 1) + RVQ_KH + 2 * (size_t)D * 32 + 8 * 32 + 2 * 32) * sizeof(float);
+    if (N >= 1024 && D % 4 == 0 && K % 32 == 0 && lds_mfma <= 160 * 1024)
+        return launch_rvq_mfma(z, books, q_out, idx_out, B, D, T, nb, K, update_residual, s);
     return N >= 4096 ? launch_rvq_t<32>(z, books, q_out, idx_out, B, D, T, nb, K, update_residual, s)
                      : launch_rvq_t<8>(z, books, q_out, idx_out, B, D, T, nb, K, update_residual, s);
 }

@@ -141,7 +141,8 @@ def test_weight_norm_bit_exact(orc, dev):
 
 @pytest.mark.parametrize("B,T,nb,K,use", [(6, 16, 3, 128, None), (2, 11, 10, 128, 7), (3, 16, 8, 512, None),
                                          (1, 75, 4, 256, 2), (5, 16, 1, 512, None), (2, 1, 2, 64, None),
-                                         (40, 103, 2, 512, None)])   # >= 4096 tokens: 32-token blocks
+                                         (40, 103, 2, 512, None),    # >= 1024 tokens: the MFMA form of the search
+                                         (64, 16, 8, 512, None), (70, 16, 3, 128, 2), (67, 16, 10, 256, None), (14, 75, 2, 512, None)])
 def test_rvq_ema_forward_bit_exact(B, T, nb, K, use, orc, dev):
     from multimodal_vqvae_compression_audio_tactile_amd import ops
     r = _rng(B * 1000 + K + nb)
@@ -160,14 +161,15 @@ def test_rvq_ema_forward_ties_pick_lowest_index(orc, dev):
     D, K = 96, 512
     book = r.standard_normal((K, D)).astype(np.float32) / math.sqrt(D)
     book[300] = book[17]; book[499] = book[17]; book[40] = book[17]     # exact duplicates
-    z = np.repeat(book[17][None, :, None], 5, axis=2).astype(np.float32)  # query == that code
-    q, idx = ops.rvq_ema_forward(_t(z, dev), _t(book[None], dev), return_indices=True)
-    _, want = orc.rvq_ema_forward(z, [book])
-    assert np.array_equal(idx.cpu().numpy(), want.astype(np.int64))
-    assert (idx.cpu().numpy() == 17).all()
+    for T in (5, 1100):                                                  # scalar form / MFMA form (>= 1024 tokens)
+        z = np.repeat(book[17][None, :, None], T, axis=2).astype(np.float32)   # query == that code
+        q, idx = ops.rvq_ema_forward(_t(z, dev), _t(book[None], dev), return_indices=True)
+        _, want = orc.rvq_ema_forward(z, [book])
+        assert np.array_equal(idx.cpu().numpy(), want.astype(np.int64))
+        assert (idx.cpu().numpy() == 17).all()
 
 
-@pytest.mark.parametrize("B,T,nb,K", [(6, 75, 3, 128), (2, 75, 8, 512)])
+@pytest.mark.parametrize("B,T,nb,K", [(6, 75, 3, 128), (2, 75, 8, 512), (16, 75, 2, 512)])
 def test_rvq_ema_step_bit_exact(B, T, nb, K, orc, dev):
     from multimodal_vqvae_compression_audio_tactile_amd import ops
     r = _rng(77 + K)
