@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_kernel(
         __syncthreads();
         // gather + straight-through sum + residual update (reads the row-major global book: contiguous row)
         for (int i = tid; i < D * RVQ_TOKS; i += 256) {
-            const int d = i % D, tok = i / D;
+            const int tok = i % RVQ_TOKS, d = i / RVQ_TOKS;          // token fastest: conflict-free LDS rows (the code rows are L2 hits)
             int id = best_i[tok];
             if (id < 0 || id >= K) id = 0;                       // all-NaN scores: defined, in-range gather
             const float q = emb[(size_t)id * D + d];
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_mfma_kernel(
         }
         __syncthreads();
         for (int i = tid; i < D * TOKS; i += 256) {
-            const int d = i % D, tok = i / D;
+            const int tok = i % TOKS, d = i / TOKS;                  // token fastest: conflict-free LDS rows (the code rows are L2 hits)
             int id = best_i[tok];
             if (id < 0 || id >= K) id = 0;
             const float q = emb[(size_t)id * D + d];
