@@ -7,7 +7,11 @@ hipError_t launch_conv_k1k3(const ConvArgs& a, int ks, int bm, hipStream_t s)
         if (bm != 96 && conv_prefer_small_tiles(a)) return launch_conv1d_mfma<1, 1, 1, 32, 1, 1, 2, 2, 0>(a, s);
         switch (bm) {
             case 128: return launch_conv1d_mfma<1, 1, 1, 16, 2, 2, 2, 2, 0>(a, s);
-            case 96:  return launch_conv1d_mfma<1, 1, 1, 16, 3, 1, 1, 4, 0>(a, s);   // 142 VGPRs -> 3 waves/SIMD: +11 % on the C = 192 layer
+            case 96:  // 16-channel stages: 3 blocks per CU (+11 % on the C = 192 layer); a grid that cannot fill the CUs anyway
+                      // (proj_down on a handful of tokens) takes 32-channel stages: half the trips through the K loop
+                      return (long)a.B * ((a.Ncols + 127) / 128) * ((a.Mrows + 95) / 96) < 200
+                                 ? launch_conv1d_mfma<1, 1, 1, 32, 3, 1, 1, 4, 0>(a, s)
+                                 : launch_conv1d_mfma<1, 1, 1, 16, 3, 1, 1, 4, 0>(a, s);
             case 64:  return launch_conv1d_mfma<1, 1, 1, 32, 2, 2, 1, 4, 0>(a, s);
         }
     } else if (ks == 3) {

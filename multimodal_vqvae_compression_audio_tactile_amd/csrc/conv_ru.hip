@@ -5,10 +5,14 @@ namespace mvq {
 template <int DIL>
 static hipError_t ru(const ConvArgs& a, int c, hipStream_t s)
 {
+    // Latency regime (the wide-tile grid would leave most CUs idle: one segment, or a few): half-width time tiles -- twice the
+    // blocks, each with half the MFMA chain.  (At full batch the wide tiles win: more operand reuse per LDS read.)
+    const long wide_blocks = (long)a.B * ((a.Ncols + (c == 64 ? 255 : 127)) / (c == 64 ? 256 : 128));
+    const bool narrow = wide_blocks < 200 && !a.name_out;
     switch (c) {
-        case 128: return launch_residual_unit<DIL, 8, 2, 2, 2, 2>(a, s);
+        case 128: return narrow ? launch_residual_unit<DIL, 4, 2, 1, 2, 2>(a, s) : launch_residual_unit<DIL, 8, 2, 2, 2, 2>(a, s);
         case 96:  return launch_residual_unit<DIL, 4, 3, 1, 1, 4>(a, s);
-        case 64:  return launch_residual_unit<DIL, 8, 2, 2, 1, 4>(a, s);
+        case 64:  return narrow ? launch_residual_unit<DIL, 8, 2, 1, 1, 4>(a, s) : launch_residual_unit<DIL, 8, 2, 2, 1, 4>(a, s);
     }
     return hipErrorInvalidValue;
 }
