@@ -324,8 +324,10 @@ hipError_t launch_convtr_direct(const DirectConvArgs& a, hipStream_t s)
 // (conflict-free: lane = token), and all 256 threads normalise and store coalesced.
 // Fallback (C too large for LDS): one thread per token straight from global memory.
 // ------------------------------------------------------------------------------------------------
-constexpr int LN_TOK = 32;
+// LN_TOK tokens per block: 32 for throughput; 4 when there are only a few tokens (one AR chunk of one segment): the block's
+// staging and normalise passes shrink 8x and 8x more blocks share the work -- the ordered per-token chain is unchanged.
 
+template <int LN_TOK>
 __global__ __launch_bounds__(256) void layernorm_c_tile_kernel(
     const float* __restrict__ x, const float* __restrict__ pe, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ y, int B, int C, int T, size_t sb, size_t sc,
@@ -446,17 +448,24 @@ hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamm
 {
     const int n = B * T;
     if (n == 0) return hipSuccess;
-    const size_t lds = ((size_t)C * LN_TOK + 2 * LN_TOK) * sizeof(float);
+    const size_t lds = ((size_t)C * 32 + 2 * 32) * sizeof(float);
     if (lds <= 160 * 1024) {
         static bool attr = false;
         if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_c_tile_kernel),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_c_tile_kernel<32>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_c_tile_kernel<4>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             attr = true;
         }
-        hipLaunchKernelGGL(layernorm_c_tile_kernel, dim3((n + LN_TOK - 1) / LN_TOK), dim3(256), lds, s,
-                           x, pe, gamma, beta, y, B, C, T, sb, sc, eps, do_tanh, post_scale, sub);
+        if (n <= 64)
+            hipLaunchKernelGGL(layernorm_c_tile_kernel<4>, dim3((n + 3) / 4), dim3(256), ((size_t)C * 4 + 8) * sizeof(float), s,
+                               x, pe, gamma, beta, y, B, C, T, sb, sc, eps, do_tanh, post_scale, sub);
+        else
+            hipLaunchKernelGGL(layernorm_c_tile_kernel<32>, dim3((n + 31) / 32), dim3(256), lds, s,
+                               x, pe, gamma, beta, y, B, C, T, sb, sc, eps, do_tanh, post_scale, sub);
     } else {
         hipLaunchKernelGGL(layernorm_c_kernel, dim3((n + 63) / 64), dim3(64), 0, s, x, pe, gamma, beta, y, B, C, T, sb, sc,
                            eps, do_tanh, post_scale, sub);
