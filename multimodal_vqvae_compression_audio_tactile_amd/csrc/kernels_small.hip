@@ -228,13 +228,24 @@ __global__ __launch_bounds__(256) void conv1d_cout1_kernel(DirectConvArgs a)
     if (t0 >= a.Tout) return;
     const float* xb = a.x + (size_t)b * a.Cin * a.Tin;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool vec = KS == 7 && a.pad == 3 && (a.Tin & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) && t0 + 3 < a.Tin;
     for (int ci = 0; ci < a.Cin; ++ci) {
         const float* xr = xb + (size_t)ci * a.Tin;
         float xv[KS + 3];
+        if (vec) {                                       // pad == 3, rows 16-byte aligned: the window t0-3 .. t0+6 sits inside
+            typedef float v4 __attribute__((ext_vector_type(4)));          // the three aligned quads t0-4, t0, t0+4
+            const v4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            const v4 q0 = t0 >= 4 ? *reinterpret_cast<const v4*>(xr + t0 - 4) : z4;
+            const v4 q1 = *reinterpret_cast<const v4*>(xr + t0);
+            const v4 q2 = t0 + 4 < a.Tin ? *reinterpret_cast<const v4*>(xr + t0 + 4) : z4;
+            xv[0] = q0.y; xv[1] = q0.z; xv[2] = q0.w; xv[3] = q1.x; xv[4] = q1.y; xv[5] = q1.z; xv[6] = q1.w;
+            xv[7] = q2.x; xv[8] = q2.y; xv[9] = q2.z;
+        } else {
 #pragma unroll
-        for (int i = 0; i < KS + 3; ++i) {
-            const int g = t0 - a.pad + i;
-            xv[i] = (g >= 0 && g < a.Tin) ? xr[g] : 0.0f;
+            for (int i = 0; i < KS + 3; ++i) {
+                const int g = t0 - a.pad + i;
+                xv[i] = (g >= 0 && g < a.Tin) ? xr[g] : 0.0f;
+            }
         }
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
