@@ -344,6 +344,18 @@ def main():
                                                   "ms_per_step": 1e3 * v["seconds"] / args.steps,
                                                   "launches_per_step": v["launches"] // args.steps}
                                               for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])}}
+            # achieved HBM rate of the conv stacks: PMC bytes per launch (profiles/pmc_traffic.json, collected on this same
+            # command as the MI355X guide prescribes) x the launches timed here, over their summed HIP-event durations
+            try:
+                pmc_all = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+                by = sum(pmc_all[k]["hbm_bytes_per_launch"] * v["launches"] for k, v in summ.items() if k in pmc_all)
+                cov = sum(v["seconds"] for k, v in summ.items() if k in pmc_all) / conv_s
+                if cov > 0.95:
+                    line["conv_stack"]["hbm"] = {"achieved_GBps": by / conv_s * 1e-9, "peak_GBps": 8000.0,
+                                                 "frac": by / conv_s * 1e-9 / 8000.0,
+                                                 "GB_per_step": by / args.steps * 1e-9, "source": "profiles/pmc_traffic.json"}
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = (cpu_baseline_train(args.books, args.embed, sd) if train else
