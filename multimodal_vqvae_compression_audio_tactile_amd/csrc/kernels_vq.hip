@@ -261,19 +261,34 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_mfma_kernel(
             __syncthreads();
             // this wave's 32-code row blocks: mb = wave, wave + 4, ... (ascending, so the strict compare keeps the lowest index)
             float bs = -__builtin_inff(); int bi = 0x7fffffff;
-            for (int mb = wave; mb * 32 < kh; mb += 4) {
-                rvq_f32x16 acc;
+            // two row blocks at a time: two independent accumulator chains keep the MFMA pipe issuing back to back (a single
+            // chain waits ~80 cycles per step for its own previous result)
+            for (int mb = wave; mb * 32 < kh; mb += 8) {
+                const bool two = (mb + 4) * 32 < kh;
+                rvq_f32x16 acc0, acc1;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                const float* ap = Es + (size_t)(mb * 32 + l31) * DP + h;
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+                const float* ap0 = Es + (size_t)(mb * 32 + l31) * DP + h;
+                const float* ap1 = Es + (size_t)((two ? mb + 4 : mb) * 32 + l31) * DP + h;
                 const float* bp = resT + h * TOKS + l31;
-                for (int sx = 0; sx < D / 2; ++sx)                           // K index = dimension, two per step
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * sx], bp[2 * sx * TOKS], acc, 0, 0, 0);
+                for (int sx = 0; sx < D / 2; ++sx) {                         // K index = dimension, two per step
+                    const float b = bp[2 * sx * TOKS];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap0[2 * sx], b, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap1[2 * sx], b, acc1, 0, 0, 0);
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int code = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float sc = acc[r] - hn[code];
+                    const float sc = acc0[r] - hn[code];
                     if (sc > bs) { bs = sc; bi = k0 + code; }
+                }
+                if (two) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int code = (mb + 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const float sc = acc1[r] - hn[code];
+                        if (sc > bs) { bs = sc; bi = k0 + code; }
+                    }
                 }
             }
             {   // the other lane half holds the other 16 rows of every block for the same token
