@@ -1,7 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- encode + VQ + decode throughput of the MI355X path (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU over RCCL.  Either the caller starts the ranks (python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N: RANK / LOCAL_RANK / WORLD_SIZE in the environment) or a bare
+``python bench.py --gpus N`` starts them itself: the parent process makes no GPU call, spawns torch.distributed.run as a
+child with the same arguments and exits with its code (rank 0's JSON line passes through on stdout).  With N distinct
+devices RCCL must come up: every rank joins one all-reduce of ones and the result (``rccl_ranks`` in the line) must equal
+N, otherwise the job prints the cause and exits non-zero -- there is no silent fallback.  gloo carries the collectives only
+in the explicit one-device rehearsal (MVQ_BENCH_ONE_DEVICE=1 or --backend gloo: every rank on cuda:0).
 
 One "step" = one pass of the hot path over one batch of synthetic paired segments that is already resident in
 HBM: ProposedEval.forward_eval (A_ENC + 32-book A_QUANT + T_ENC + 5 AR chunks with 8x512 RVQ + T_DEC) over
@@ -50,6 +58,9 @@ def parse():
     ap.add_argument("--embed", type=int, default=512)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo for a "
                     "single-GPU rehearsal of the multi-rank path together with MVQ_BENCH_ONE_DEVICE=1)")
+    ap.add_argument("--force-collectives", action="store_true", help="issue the training collectives even in a 1-rank group "
+                    "(lets a one-GPU box execute the RCCL code path under torch.distributed.run --nproc-per-node 1)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 latency section (reference protocol)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline = null)")
     return ap.parse_args()
@@ -187,43 +198,130 @@ def cpu_baseline_train(books, embed, sd):
                       f"restatement + autograd + AdamW (codebook EMA not included), {threads} threads"}
 
 
+def self_launch(args) -> int:
+    """Bare ``python bench.py --gpus N`` (N > 1, no WORLD_SIZE): start the N ranks as a child job.  This process has made
+    no GPU call (device_count() does not initialise HIP on this image) and never execs: it waits and returns the child's code."""
+    import socket
+    import subprocess
+    one_dev = os.environ.get("MVQ_BENCH_ONE_DEVICE") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and not one_dev:
+        print(f"bench.py: --gpus {args.gpus} but only {ndev} HIP device(s) visible (set MVQ_BENCH_ONE_DEVICE=1 for the "
+              "one-device rehearsal of the multi-rank path)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes on this pool)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def fatal(rank, msg, code=3):
+    """A rank that cannot continue: say why and leave at once (torch.distributed.run then stops the other ranks) --
+    never sit in a collective the others will not reach."""
+    print(f"[bench rank {rank}] FATAL: {msg}", file=sys.stderr, flush=True)
+    os._exit(code)
+
+
+def pmc_traffic_table():
+    """profiles/pmc_traffic.json (HBM bytes per launch per kernel, from two rocprofv3 --pmc passes of this same command,
+    tools/pmc_traffic.py) + where it came from: the commit it was profiled at and whether csrc/ still has the same content."""
+    f = ROOT / "profiles" / "pmc_traffic.json"
+    if not f.exists():
+        return {}, None
+    try:
+        tab = json.loads(f.read_text())
+    except Exception:
+        return {}, None
+    meta = tab.pop("_meta", {}) if isinstance(tab, dict) else {}
+    from tools.pmc_traffic import csrc_digest
+    now = csrc_digest(ROOT)
+    src = {"file": "profiles/pmc_traffic.json", "profiled_at_commit": meta.get("commit"),
+           "csrc_sha16_profiled": meta.get("csrc_sha16"), "csrc_sha16_now": now,
+           "kernels_unchanged_since_profile": bool(meta.get("csrc_sha16")) and meta.get("csrc_sha16") == now}
+    return tab, src
+
+
+def latency_b1(mvq, synth, dev, books, embed, sd):
+    """B = 1 latency in the reference's own protocol (Evaluation/dac_vcpwq_proposed6_latency.py:489-525): 1 s of zeros,
+    3 warm-ups, 10 repeats, device synchronised before each clock read; encode_latents and T_DEC timed separately."""
+    net = mvq.build_proposed(sd, rvq_books=books, rvq_embed=embed, device=dev)
+    a = torch.zeros(1, 1, 24000, device=dev); t = torch.zeros(1, 1, 24000, device=dev)
+    for _ in range(3):
+        z = net.encode_latents(a, t, books_use=books); net.T_DEC(z)
+    torch.cuda.synchronize()
+    enc, dec = [], []
+    for _ in range(10):
+        t0 = time.perf_counter(); z = net.encode_latents(a, t, books_use=books); torch.cuda.synchronize()
+        enc.append((time.perf_counter() - t0) * 1e3)
+    for _ in range(10):
+        t0 = time.perf_counter(); net.T_DEC(z); torch.cuda.synchronize()
+        dec.append((time.perf_counter() - t0) * 1e3)
+    return {"encode_ms": sum(enc) / len(enc), "decode_ms": sum(dec) / len(dec), "encode_min_ms": min(enc), "decode_min_ms": min(dec),
+            "protocol": "B=1, 1 s of zeros @ 24 kHz, 3 warm-ups + 10 repeats, sync before each clock read; fp32 exact path",
+            "reference_published": {"encode_ms": [12.8, 16.3], "decode_ms": [2.75, 2.86], "hardware": "unstated CUDA GPU, AMP",
+                                    "source": "Evaluation/eval_vs_dac24_with_vcpwq_rawPSNR_latency/eval_all_vs_dac24_vcpwq_rawPSNR_latency.json:89-90"}}
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong GPU count", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP device); there is no CPU fallback for the product path")
-    if os.environ.get("MVQ_BENCH_ONE_DEVICE") == "1":     # rehearsal: every rank on cuda:0 (never on the 8-GPU node)
+    one_dev = os.environ.get("MVQ_BENCH_ONE_DEVICE") == "1"      # rehearsal: every rank on cuda:0 (never on the 8-GPU node)
+    if one_dev:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        fatal(rank, f"LOCAL_RANK {local_rank} has no device ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist, grp, backend_used = None, None, None
-    if world > 1:
-        # The rendezvous and the agreement on the backend go over gloo (host only: cannot fail for GPU reasons); RCCL is
-        # then brought up as a group of its own and PROVEN with one all-reduce.  Every rank reports over gloo whether that
-        # worked; unless all did, the whole job keeps gloo for its barriers / timing reduction instead of dying or hanging
-        # half-initialised.  (Inference has no data-path collective at all; training all-reduces 34 MB of gradients.)
+    under_launcher = "WORLD_SIZE" in os.environ
+    dist, grp, backend_used, rccl_ranks = None, None, None, None
+    if under_launcher:
+        # The rendezvous goes over gloo (host only: cannot fail for GPU reasons and gives every rank a way to learn that a
+        # peer died).  The data-path group is RCCL and has to PROVE itself: one all-reduce of ones must return the world
+        # size on every rank.  Failure is fatal (the rank exits non-zero, the launcher stops the job).
         import datetime
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
-        backend_used = "gloo"
-        if args.backend == "nccl":
-            ok = 0
+        use_gloo = one_dev or args.backend == "gloo"
+        if world > 1 and not one_dev and args.backend == "gloo":
+            print(f"[bench rank {rank}] --backend gloo with distinct devices: collectives go over the host", file=sys.stderr)
+        if use_gloo:
+            backend_used = "gloo (one-device rehearsal)" if one_dev else "gloo"
+        else:
             try:
-                g = dist.new_group(backend="nccl")
+                grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
                 probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe, group=g)
+                dist.all_reduce(probe, group=grp)
                 torch.cuda.synchronize()
-                ok = int(round(float(probe.item())) == world)
-            except Exception as ex:                                      # e.g. two ranks on one device in a rehearsal
-                print(f"[bench rank {rank}] RCCL group unavailable ({type(ex).__name__}); using gloo for control", file=sys.stderr)
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                grp, backend_used = g, "nccl"
+                rccl_ranks = int(round(float(probe.item())))
+            except Exception as ex:
+                fatal(rank, f"RCCL group did not come up ({type(ex).__name__}: {ex})")
+            if rccl_ranks != world:
+                fatal(rank, f"RCCL all-reduce of ones returned {rccl_ranks}, expected {world}")
+            backend_used = "nccl"
     red_dev = dev if backend_used == "nccl" else torch.device("cpu")
+
+    def barrier():
+        if dist is None:
+            return
+        if backend_used == "nccl":
+            dist.barrier(group=grp, device_ids=[local_rank])
+        else:
+            dist.barrier()
 
     import multimodal_vqvae_compression_audio_tactile_amd as mvq
     from multimodal_vqvae_compression_audio_tactile_amd import ops, synth
@@ -238,6 +336,7 @@ def main():
 
     if train:
         from multimodal_vqvae_compression_audio_tactile_amd import dist as mdist
+        mdist.FORCE_COLLECTIVES = bool(args.force_collectives)
         net.train()                                              # ctx dropout on, as in the reference's epoch loop
         crit = mvq.TrainingLoss()
         params = [p for n, p in net.named_parameters() if p.requires_grad and not n.startswith("vq.books")]
@@ -275,19 +374,19 @@ def main():
     if not args.no_kernel_events and not train:           # the train step has ~600 small launches: the per-launch host cost
         kev = KernelEvents(); kev.wrap(ops)               # of the event wrappers would be what gets measured
 
-    if dist: dist.barrier(group=grp)
+    barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y = step()
     torch.cuda.synchronize()
-    if dist: dist.barrier(group=grp)
+    barrier()
     elapsed = time.perf_counter() - t0
     if kev: kev._restore()
 
     if dist:
         tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=grp)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=grp)              # grp is None (default gloo group) in the rehearsal
         elapsed = float(tt.item())
 
     out_ok = bool(torch.isfinite(y).all().item()) and y.shape[0] == B
@@ -300,7 +399,7 @@ def main():
             "value": seg_s * TOKENS_PER_SEGMENT, "unit": "token-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "segments_per_s": seg_s, "output_finite": out_ok,
+            "segments_per_s": seg_s, "output_finite": out_ok, "rccl_ranks": rccl_ranks,
             "config": {"workload": ("joint audio+tactile ProposedEval.forward_eval (compare_dacvsproposal_5 config: "
                                     "2x DAC-24k encoder, 32x1024x8 audio RVQ, CrossPredictor AR x5 chunks, "
                                     f"RVQ {args.books}x{args.embed}x96, DAC-24k decoder)") if not tact else
@@ -308,7 +407,7 @@ def main():
                                     "-> proj_up -> T_DEC"),
                        "segments_per_gpu_per_step": B, "segment": "1 s @ 24 kHz = 75 token-frames",
                        "sharding": f"segments sharded over {world} GPU(s), no data-path collective",
-                       "collective_backend": backend_used,
+                       "collective_backend": backend_used, "rccl_ranks": rccl_ranks,
                        "weights": "seeded variance-preserving random init of the DAC-24k architecture"},
         }
         if train:
@@ -326,15 +425,11 @@ def main():
             dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
             name, d = dom
             ach = d["flops"] / d["seconds"] * 1e-12
-            traffic = None
-            pmc = ROOT / "profiles" / "pmc_traffic.json"
-            if pmc.exists():
-                try:
-                    traffic = json.loads(pmc.read_text()).get(name, {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            pmc_all, pmc_src = pmc_traffic_table()
+            traffic = pmc_all.get(name, {}).get("hbm_bytes_per_launch")       # null when this kernel is not in the profile
             line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                                "traffic_source": pmc_src if traffic is not None else None,
                                 "launches": d["launches"], "avg_launch_us": 1e6 * d["seconds"] / d["launches"],
                                 "flop_per_launch": d["flops"] / d["launches"],
                                 "share_of_conv_time": d["seconds"] / sum(v["seconds"] for v in summ.values())}
@@ -346,16 +441,18 @@ def main():
                                               for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])}}
             # achieved HBM rate of the conv stacks: PMC bytes per launch (profiles/pmc_traffic.json, collected on this same
             # command as the MI355X guide prescribes) x the launches timed here, over their summed HIP-event durations
-            try:
-                pmc_all = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+            if pmc_all:
                 by = sum(pmc_all[k]["hbm_bytes_per_launch"] * v["launches"] for k, v in summ.items() if k in pmc_all)
                 cov = sum(v["seconds"] for k, v in summ.items() if k in pmc_all) / conv_s
                 if cov > 0.95:
                     line["conv_stack"]["hbm"] = {"achieved_GBps": by / conv_s * 1e-9, "peak_GBps": 8000.0,
                                                  "frac": by / conv_s * 1e-9 / 8000.0,
-                                                 "GB_per_step": by / args.steps * 1e-9, "source": "profiles/pmc_traffic.json"}
-            except Exception:
-                pass
+                                                 "GB_per_step": by / args.steps * 1e-9, "source": pmc_src}
+        if world == 1 and not train and not args.no_latency:
+            try:
+                line["latency_b1"] = latency_b1(mvq, synth, dev, args.books, args.embed, sd)
+            except Exception as ex:
+                line["latency_b1"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = (cpu_baseline_train(args.books, args.embed, sd) if train else

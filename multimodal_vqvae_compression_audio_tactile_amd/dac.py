@@ -61,7 +61,20 @@ class Snake1d(nn.Module):
         return self.alpha.detach().reshape(-1).float().contiguous()
 
 
-class WNConv1d(nn.Module):
+class _WNKeys:
+    """Accept both spellings of a weight-normed layer in a checkpoint: the old hook-based ``weight_g`` / ``weight_v``
+    (torch.nn.utils.weight_norm -- what upstream DAC releases and the reference's best.pth hold) and the parametrization
+    spelling ``parametrizations.weight.original0`` (= g) / ``original1`` (= v) that newer torch writes when the same model
+    is re-saved through torch.nn.utils.parametrizations.weight_norm.  state_dict() always emits the old names."""
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for new, old in (("parametrizations.weight.original0", "weight_g"), ("parametrizations.weight.original1", "weight_v")):
+            if prefix + new in state_dict and prefix + old not in state_dict:
+                state_dict[prefix + old] = state_dict.pop(prefix + new)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class WNConv1d(_WNKeys, nn.Module):
     """weight_norm(nn.Conv1d) parameter holder (old-style names weight_g / weight_v / bias)."""
 
     def __init__(self, cin, cout, kernel_size, stride=1, dilation=1, padding=0):
@@ -100,7 +113,7 @@ class WNConv1d(nn.Module):
         return self.run(x)
 
 
-class WNConvTranspose1d(nn.Module):
+class WNConvTranspose1d(_WNKeys, nn.Module):
     """weight_norm(nn.ConvTranspose1d) parameter holder; weight_v is [Cin, Cout, k], norm over dim 0."""
 
     def __init__(self, cin, cout, kernel_size, stride, padding):
@@ -426,12 +439,24 @@ class DAC(nn.Module):
         self.decoder = Decoder(latent_dim, decoder_dim, decoder_rates)
 
     @classmethod
-    def load(cls, path, **kw):
-        """Load a LOCAL state dict (there is no downloader: the reference's dac.utils.download is a network fetch)."""
+    def load(cls, path, strict: bool = True, **kw):
+        """Load a LOCAL checkpoint (there is no downloader: the reference's dac.utils.download is a network fetch).
+        Accepted layouts: upstream's ``{"state_dict": ..., "metadata": {"kwargs": {...}}}`` (audiotools BaseModel.save --
+        the constructor arguments stored there are honoured, explicit ``**kw`` override them, as upstream's
+        BaseModel.load does; this is what sets ``quantizer_dropout``, which matters under ``net.train()``), a bare
+        ``{"state_dict": ...}``, or a plain state dict.  Either weight-norm key spelling loads (see _WNKeys)."""
+        import inspect
         obj = torch.load(str(path), map_location="cpu")
         sd = obj.get("state_dict", obj) if isinstance(obj, dict) else obj
-        model = cls(**kw)
-        model.load_state_dict(sd, strict=True)
+        kwargs = {}
+        meta = obj.get("metadata") if isinstance(obj, dict) else None
+        if isinstance(meta, dict) and isinstance(meta.get("kwargs"), dict):
+            accepted = set(inspect.signature(cls.__init__).parameters) - {"self"}
+            kwargs = {k: v for k, v in meta["kwargs"].items() if k in accepted}
+        kwargs.update(kw)
+        model = cls(**kwargs)
+        model.load_state_dict(sd, strict=strict)
+        model.metadata = meta
         return model
 
     @torch.no_grad()

@@ -20,6 +20,14 @@ from typing import List, Tuple
 
 import torch
 
+FORCE_COLLECTIVES = False     # True: issue the collectives even in a 1-rank group (lets a one-GPU box execute the RCCL path)
+
+
+def _skip(dist, group) -> bool:
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES
+
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [start, end) slice of n_items for `rank` (sizes differ by at most one)."""
@@ -39,7 +47,7 @@ def gather_tokens(r_tokens: torch.Tensor, group=None) -> torch.Tensor:
     """All-gather [B,D,T] token tensors along the batch axis in rank order (every rank gets the same tensor).
     Per-rank batch sizes may differ (uneven shards): sizes are exchanged first."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _skip(dist, group):
         return r_tokens
     world = dist.get_world_size(group)
     r_tokens = r_tokens.contiguous()
@@ -66,7 +74,7 @@ def allreduce_grads(params, local_items: int, group=None) -> None:
     """Make every rank's ``.grad`` the gradient of the GLOBAL-batch mean loss: one flat-bucket all-reduce.
     Call between ``total.backward()`` and ``clip_grad_norm_`` / ``opt.step()`` (Training/...5.py:393-395)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _skip(dist, group):
         return
     params = [p for p in params if p.grad is not None]
     if not params:

@@ -208,28 +208,34 @@ class _ProposedBase(nn.Module):
         return min(max(self._scale_raw(), 5e-3), 0.5)
 
     @torch.no_grad()
-    def _ar_latents(self, qa, zt, books_use=None, want_tokens=False, tactile_only=False):
-        """The chunked AR loop (Training/...5.py:302-320 == Evaluation/...6_latency.py:461-477)."""
+    def _ar_latents(self, qa, zt, books_use=None, want_tokens=False, tactile_only=False, want_indices=False):
+        """The chunked AR loop (Training/...5.py:302-320 == Evaluation/...6_latency.py:461-477).
+        ``want_indices``: also return the per-book code indices idx[n_books_use, B, Tlat] (int64)."""
         B, C, Tlat = zt.shape
         z_run = torch.zeros_like(zt)
         r_tokens = torch.empty(B, CODE_DIM, Tlat, device=zt.device, dtype=torch.float32) if want_tokens else None
+        idx_all = [] if want_indices else None
         if B == 0 or Tlat == 0:                                               # empty batch / clip shorter than a token
-            return z_run, r_tokens
+            return (z_run, r_tokens, torch.zeros(0, B, Tlat, dtype=torch.int64, device=zt.device)) if want_indices \
+                else (z_run, r_tokens)
         scale = self._scale_value()
         ln = self.tokennorm.ln
+        books = self.vq.stacked() if len(self.vq.books) else None             # ONE stack per call, not one per chunk
         kv_all = None
         if not tactile_only:
             Ta = min(qa.shape[-1], Tlat)                                      # audio may be shorter (whole-file mode)
             if Ta > 0:                                                        # K, V of all chunks up front (3 launches)
                 kv_all = self.predict.keys_values(ops.fold_time_slice(qa, 0, Ta), B, AR_CHUNK_TOK)
-        for s in range(0, Tlat, AR_CHUNK_TOK):
+        zt_prev, zp_n = None, -1      # the shift-by-one input: all zero except column 0 of each item (s > 0), so one zeroed
+        for s in range(0, Tlat, AR_CHUNK_TOK):                               # buffer per chunk width serves every chunk
             e = min(Tlat, s + AR_CHUNK_TOK)
             n = e - s
             zt_c = ops.fold_time_slice(zt, s, e)                             # [1,C,B*n]
             if tactile_only:
                 z_pred = None
             else:
-                zt_prev = torch.zeros(1, C, B * n, device=zt.device, dtype=torch.float32)
+                if n != zp_n:
+                    zt_prev, zp_n = torch.zeros(1, C, B * n, device=zt.device, dtype=torch.float32), n
                 if s > 0:                                                     # column 0 <- z_run[..., s-1]
                     ops.fold_column_into_(zt_prev, 0, z_run, s - 1, B)
                 ka = min(qa.shape[-1], e) - min(qa.shape[-1], s)
@@ -240,11 +246,19 @@ class _ProposedBase(nn.Module):
             rN = ops.layernorm_c(zt_c, ln.weight.detach(), ln.bias.detach(), eps=ln.eps, do_tanh=True, post_scale=scale,
                                  folded_batch=B, sub=z_pred)                  # tanh(TokenNorm(zt - z_pred)) * scale
             rD = self._pd(rN)                                                 # [1,96,B*n]
-            qD = self.vq(rD, n_books_use=books_use)
+            if books is None:
+                qD = torch.zeros_like(rD)
+            elif want_indices:
+                qD, idx = ops.rvq_ema_forward(rD, books, books_use, return_indices=True)
+                idx_all.append(idx.reshape(idx.shape[0], B, n))
+            else:
+                qD = ops.rvq_ema_forward(rD, books, books_use)
             z_hat = self._pu(qD, residual=z_pred)
             ops.unfold_into_(z_run, s, z_hat, B)
             if want_tokens:
                 ops.unfold_into_(r_tokens, s, rD, B)
+        if want_indices:
+            return z_run, r_tokens, torch.cat(idx_all, dim=2) if idx_all else torch.zeros(0, B, Tlat, dtype=torch.int64)
         return z_run, r_tokens
 
     TWO_STREAM_MAX_BATCH = 64     # up to this many segments the two encoder branches run on two HIP streams (measured:
@@ -272,6 +286,14 @@ class _ProposedBase(nn.Module):
             x.record_stream(cur)
         return qa, zt
 
+    @torch.no_grad()
+    def encode_latents_with_indices(self, a_1T, t_1T, books_use=None):
+        """encode_latents plus what a transmitter would send: -> (z_run, audio codes[B,32,Ta] of A_QUANT, RVQ idx[n_books_use,B,Tlat])."""
+        za = self.A_ENC(a_1T)
+        qa, codes, *_ = self.A_QUANT(za)
+        z_run, _, idx = self._ar_latents(qa, self.T_ENC(t_1T), books_use, want_indices=True)
+        return z_run, codes, idx
+
     def _ar_latents_train(self, qa, zt):
         """The same loop recorded for autograd: z_hat of chunk c feeds column 0 of chunk c+1's zt_prev WITH gradient
         (the reference writes z_hat into z_run in place and slices it back, Training/...5.py:303-319)."""
@@ -279,6 +301,7 @@ class _ProposedBase(nn.Module):
         dev = zt.device
         ln = self.tokennorm.ln
         scale_raw = self._scale_raw()
+        books = self.vq.stacked()
         chunks, r_toks, prev = [], [], None
         for s in range(0, Tlat, AR_CHUNK_TOK):
             e = min(Tlat, s + AR_CHUNK_TOK)
@@ -296,7 +319,7 @@ class _ProposedBase(nn.Module):
             u = train.LayerNormC.apply(r, ln.weight, ln.bias, None, ln.eps, B)
             rN = train.ScaleTanh.apply(u, self.scale, scale_raw)
             rD = train.Linear.apply(rN, self.proj_down.weight, self.proj_down.bias, None, self._pd)
-            qD = train.RvqSte.apply(rD, self.vq.stacked(), None)
+            qD = train.RvqSte.apply(rD, books, None)
             z_hat = train.Linear.apply(qD, self.proj_up.weight, self.proj_up.bias, z_pred, self._pu)
             chunks.append(z_hat.reshape(C, B, n))
             r_toks.append(rD.detach().reshape(CODE_DIM, B, n))
@@ -312,8 +335,7 @@ class ProposedEval(_ProposedBase):
     @torch.no_grad()
     def encode_latents(self, a_1T, t_1T, books_use=None):
         qa, zt = self._encode_branches(a_1T, t_1T)
-        z_run, _ = self._ar_latents(qa, zt, books_use)
-        return z_run
+        return self._ar_latents(qa, zt, books_use)[0]
 
     @torch.no_grad()
     def forward_eval(self, a_1T, t_1T, books_use=None):
@@ -336,7 +358,7 @@ class AllPredAR(_ProposedBase):
     """Training/compare_dacvsproposal_5.py:279-326.  Under ``torch.no_grad()`` (validation, ...:411-414) this is the
     fused inference path; with autograd enabled it records the HIP-backed graph of train.py for ``.backward()``."""
 
-    def forward_step(self, a_1T, tc_1T):
+    def _forward_step(self, a_1T, tc_1T):
         Tw = tc_1T.shape[-1]
         with torch.no_grad():                                                  # frozen backbones: no graph
             qa, zt = self._encode_branches(a_1T, tc_1T)
@@ -349,7 +371,32 @@ class AllPredAR(_ProposedBase):
                 y_hat = self.T_DEC(z_run)
         T = min(y_hat.shape[-1], tc_1T.shape[-1], Tw)
         fz = lambda x: torch.nan_to_num(x, nan=0.0, posinf=0.0, neginf=0.0)   # finite_or_zero (...5.py:99-100)
-        return {"y_hat": fz(y_hat[..., :T]), "tgt": fz(tc_1T[..., :T]), "r_tokens": r_tokens}
+        return {"y_hat": fz(y_hat[..., :T]), "tgt": fz(tc_1T[..., :T]), "r_tokens": r_tokens}, qa, zt
+
+    def forward_step(self, a_1T, tc_1T):
+        return self._forward_step(a_1T, tc_1T)[0]
+
+
+class AllPredAR3(AllPredAR):
+    """The ``AllPredAR`` of Training/compare_dacvsproposal_3.py:278-340 (BASELINE.json configs[0]): same model, but the
+    constructor takes no sweep arguments (the script's module constants RVQ_N_BOOKS = 10, RVQ_EMBED = 128, ...:61-63) and
+    ``forward_step`` additionally returns ``z_teacher`` (= T_ENC(tc), indexed by the script's ``step()``, ...:389-394) and
+    ``z_pred`` (one more ``predict()`` call on an all-zero ``zt_prev`` over the first chunk, ...:334-337 -- unused by the
+    loss, but in train mode it draws one more dropout mask, so it is issued at the same point of the RNG stream)."""
+
+    def __init__(self, A_ENC, A_QUANT, T_ENC, T_DEC, c_lat, rvq_books: int = 10, rvq_embed: int = 128, decay=EMA_DECAY):
+        super().__init__(A_ENC, A_QUANT, T_ENC, T_DEC, c_lat, rvq_books, rvq_embed, decay)
+
+    def forward_step(self, a_1T, tc_1T):
+        out, qa, zt = self._forward_step(a_1T, tc_1T)
+        Tlat = zt.shape[-1]
+        n = min(AR_CHUNK_TOK, Tlat)
+        z_pred = None
+        if Tlat > 0:
+            ka = min(qa.shape[-1], n)
+            z_pred = self.predict(torch.zeros_like(zt[..., :n]), qa[..., :ka].contiguous())
+        return {"y_hat": out["y_hat"], "tgt": out["tgt"], "z_pred": z_pred, "z_teacher": zt,
+                "r_tokens": out["r_tokens"] if Tlat > 0 else None}
 
 
 def psnr_batch(ref_1T, est_1T, eps=1e-12):

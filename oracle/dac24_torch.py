@@ -120,6 +120,8 @@ class Decoder(nn.Module):
 
 
 class VectorQuantize(nn.Module):
+    margin_log = None          # set to a list by tests/golden/make_golden.py to record arg-max margins
+
     def __init__(self, input_dim, codebook_size, codebook_dim):
         super().__init__()
         self.in_proj = WNConv1d(input_dim, codebook_dim, kernel_size=1)
@@ -134,6 +136,9 @@ class VectorQuantize(nn.Module):
         cbn = F.normalize(cb)
         dist = enc.pow(2).sum(1, keepdim=True) - 2 * enc @ cbn.t() + cbn.pow(2).sum(1, keepdim=True).t()
         idx = (-dist).max(1)[1].reshape(B, T)
+        if VectorQuantize.margin_log is not None:        # fixture generation: top-1 / top-2 gap of every arg-max
+            top = (-dist).topk(2, dim=1)[0]
+            VectorQuantize.margin_log.append(((top[:, 0] - top[:, 1]).reshape(B, T), dist.abs().amax(dim=1).reshape(B, T)))
         z_q = F.embedding(idx, cb).transpose(1, 2)
         return z_q, idx
 

@@ -54,6 +54,10 @@ def training():
     return load("Training/compare_dacvsproposal_5.py", "ref_train5")
 
 
+def training3():
+    return load("Training/compare_dacvsproposal_3.py", "ref_train3")
+
+
 def evaluation():
     return load("Evaluation/dac_vcpwq_proposed6_latency.py", "ref_eval6")
 

@@ -10,7 +10,14 @@ patched) and records inputs-by-seed + expected outputs of:
   G2 ResidualVQEMA.ema_step           (Training/compare_dacvsproposal_5.py:266-277)
   G3 CrossPredictor.forward           (Training/compare_dacvsproposal_5.py:226-244), eval mode
   G4 ProposedEval.encode_latents / forward_eval (Evaluation/dac_vcpwq_proposed6_latency.py:451-487) driven with the
-     torch restatement of the DAC backbones as A_ENC / A_QUANT / T_ENC / T_DEC (the real `dac` package is absent)
+     torch restatement of the DAC backbones as A_ENC / A_QUANT / T_ENC / T_DEC (the real `dac` package is absent).
+     Also stored: the 32-book audio ``codes`` of A_QUANT, the per-book RVQ ``idx`` the reference's ``_nearest_l2``
+     returned in every chunk (recorded by wrapping that staticmethod while encode_latents runs) and, for every one of
+     those arg-maxes, the top-1 / top-2 score gap (``margin``) -- a consumer may excuse an index mismatch only where
+     the stored margin is below a stated round-off bound.
+  G10 compare_dacvsproposal_3.py (BASELINE.json configs[0]): its own ``AllPredAR`` (Training/...3.py:278-340; 10 books x
+     K = 128 from the script's module constants) on ONE full 24 000-sample pair, B = 1, eval mode: y_hat, z_pred, z_teacher,
+     r_tokens, per-book idx + margins, and the three losses / total of the script's ``step()`` body (...3.py:383-398).
   G6 align_by_xcorr                   (Evaluation/dac_vcpwq_proposed6_latency.py:164-202)
   G7 one training step's loss and gradients: the reference's AllPredAR.forward_step (Training/...5.py:293-326) on the
      restated backbones, its MultiResSTFTLoss / MelCosineLoss / safe_l1 (...:150-211; torchaudio's MelScale replaced by
@@ -40,6 +47,50 @@ from oracle import ref_import                   # noqa: E402
 OUT = Path(__file__).resolve().parent
 torch.set_grad_enabled(False)
 torch.manual_seed(0)
+
+
+class RecordNearest:
+    """While active, ``cls._nearest_l2`` (the reference's arg-max, ...6_latency.py:417-419 / ...3.py:250-252) also logs
+    what it returned and the top-1 / top-2 gap of the scores it ranked.  calls: list of (idx[N], margin[N])."""
+
+    def __init__(self, cls):
+        self.cls, self.orig, self.calls = cls, cls.__dict__["_nearest_l2"], []
+
+    def __enter__(self):
+        orig = self.orig.__func__
+
+        def rec(x, emb):
+            idx = orig(x, emb)
+            sc = x @ emb.t() - 0.5 * (emb * emb).sum(dim=1).unsqueeze(0)
+            top = sc.topk(2, dim=1)
+            assert torch.equal(top[1][:, 0], idx) or bool((top[0][:, 0] == top[0][:, 1]).any())
+            self.calls.append((idx.clone(), (top[0][:, 0] - top[0][:, 1]).clone(), sc.abs().amax(dim=1)))
+            return idx
+        self.cls._nearest_l2 = staticmethod(rec)
+        return self
+
+    def __exit__(self, *a):
+        self.cls._nearest_l2 = self.orig
+
+    def stacked(self, n_books, B):
+        """calls arrive chunk by chunk, book by book -> idx[n_books, B, Tl] int16 and, same shape float32, margin (top-1 minus
+        top-2 score) and scale (largest |score| that arg-max ranked: the yardstick of its round-off)."""
+        chunks = [self.calls[i:i + n_books] for i in range(0, len(self.calls), n_books)]
+        cat = lambda j: torch.cat([torch.stack([c[j].reshape(B, -1) for c in ch]) for ch in chunks], -1).numpy()
+        return cat(0).astype(np.int16), cat(1).astype(np.float32), cat(2).astype(np.float32)
+
+
+def audio_codes_with_margins(dac_model, a):
+    """A_QUANT(A_ENC(a)) on the torch restatement -> codes[B,32,Tl] int16, margin[B,32,Tl] (gap of -dist, top-1 minus top-2),
+    scale[B,32,Tl] (largest |dist| ranked)."""
+    T.VectorQuantize.margin_log = []
+    try:
+        codes = dac_model.quantizer(dac_model.encoder(a))[1]
+        mar = torch.stack([m for m, _ in T.VectorQuantize.margin_log], dim=1)
+        sca = torch.stack([s for _, s in T.VectorQuantize.margin_log], dim=1)
+    finally:
+        T.VectorQuantize.margin_log = None
+    return codes.numpy().astype(np.int16), mar.numpy().astype(np.float32), sca.numpy().astype(np.float32)
 
 
 def main():
@@ -100,7 +151,10 @@ def main():
         net = ev.ProposedEval(da.encoder, da.quantizer, dt.encoder, dt.decoder, c_lat=1024, rvq_books=books, rvq_embed=K)
         net.load_state_dict(sdm, strict=True)
         net.eval()
-        z_run = net.encode_latents(a, t, books_use=use)
+        with RecordNearest(ev.ResidualVQEMA) as rec:
+            z_run = net.encode_latents(a, t, books_use=use)
+        g4[f"{name}.idx"], g4[f"{name}.margin"], g4[f"{name}.scale"] = rec.stacked(books if use is None else min(use, books), B)
+        g4[f"{name}.codes"], g4[f"{name}.codes_margin"], g4[f"{name}.codes_scale"] = audio_codes_with_margins(da, a)
         y = net.forward_eval(a, t, books_use=use)
         Tm = y.shape[-1]
         g4[f"{name}.z_run"] = z_run.numpy()
@@ -159,6 +213,29 @@ def main():
     shifts = [e5.align_pair_24k(ref[i:i + 1], est[i:i + 1])[2] for i in range(ref.shape[0])]
     np.savez_compressed(OUT / "g9_aligned_psnr.npz", psnr=np.array(e5.psnr_3k_aligned_batch(ref, est), np.float64),
                         shifts=np.array(shifts, np.int64))
+    # ---- G10: compare_dacvsproposal_3.py -- its own AllPredAR + step() body, one full segment, B = 1
+    t3 = ref_import.training3()
+    assert (t3.RVQ_N_BOOKS, t3.RVQ_EMBED, t3.CODE_DIM) == gi.CFG3[:3]
+    sdm = gi.model_state(gi.CFG3[3], t3.RVQ_N_BOOKS, t3.RVQ_EMBED)
+    a, t = gi.cfg3_inputs()
+    da, dt = T.DAC(), T.DAC()
+    net = t3.AllPredAR(da.encoder, da.quantizer, dt.encoder, dt.decoder, c_lat=1024)
+    net.load_state_dict(sdm, strict=True)
+    net.eval()
+    mr, mc = t3.MultiResSTFTLoss(), t3.MelCosineLoss()
+    mc.mel = LT.MelScale(n_mels=64, sample_rate=24000, n_stft=257, f_min=0.0, f_max=12000.0)
+    with RecordNearest(t3.ResidualVQEMA) as rec:
+        out = net.forward_step(a, t)
+    yh, tg = out["y_hat"], out["tgt"]
+    l1, st, me = t3.safe_l1(yh, tg), mr(yh, tg), mc(yh, tg)
+    total = t3.W_WAV_L1 * l1 + t3.W_STFT * st + t3.W_MELCOS * me + t3.W_LAT * 0.0          # llat = 0.0 (...3.py:389-396)
+    idx, mar, sca = rec.stacked(t3.RVQ_N_BOOKS, 1)
+    codes, cmar, csca = audio_codes_with_margins(da, a)
+    np.savez_compressed(OUT / "g10_config3.npz", y_hat=yh.numpy(), z_pred=out["z_pred"].numpy(),
+                        z_teacher=out["z_teacher"].numpy(), r_tokens=out["r_tokens"].numpy(), idx=idx, margin=mar,
+                        scale=sca, codes=codes, codes_margin=cmar, codes_scale=csca,
+                        losses=np.array([float(l1), float(st), float(me), float(total)], np.float64),
+                        psnr=np.array(e5.psnr_batch(tg, yh), np.float64))
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size // 1024, "KiB")
 

@@ -99,3 +99,16 @@ def test_sharding_covers_every_segment_once():
             assert rr == list(range(n))
     with pytest.raises(ValueError):
         mdist.shard_range(4, 2, 2)
+
+
+def test_bench_gpu_count_contract():
+    """bench.py --gpus N: a bare call with N > 1 starts its own ranks only when N devices exist (here: none -> exit 2, no
+    line), and a rank count that contradicts --gpus is refused instead of silently benchmarking another N."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MVQ_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "HIP device" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0"),
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr and not r.stdout.strip()

@@ -104,3 +104,24 @@ def test_edge_cases(model, orc, dev):
             assert torch.equal(codes[:, :prev.shape[1]], prev)                 # residual stages are nested
         prev = codes
         assert mdl.decode(z).shape == (2, 1, 23992)
+
+
+def test_hipgraph_replay_is_bit_equal_to_eager(model, dev):
+    """graphs.GraphedCall (one hipGraph per call, B = 1 latency regime): a replay -- also on NEW input values copied into the
+    captured buffers -- returns exactly what the eager launch sequence returns, for encode_latents (two-stream fork inside
+    the capture) and for the decoder."""
+    from multimodal_vqvae_compression_audio_tactile_amd import synth
+    from multimodal_vqvae_compression_audio_tactile_amd.graphs import GraphedCall
+    sd, net = model
+    a, t = synth.audio_segments(1, seed=33).to(dev), synth.tactile_segments(1, seed=33).to(dev)
+    z = net.encode_latents(a, t)
+    y = net.T_DEC(z)
+    g_enc = GraphedCall(lambda aa, tt: net.encode_latents(aa, tt), a, t)
+    g_dec = GraphedCall(lambda zz: net.T_DEC(zz), z)
+    assert torch.equal(g_enc(a, t), z) and torch.equal(g_dec(z), y)
+    a2, t2 = synth.audio_segments(1, seed=34).to(dev), synth.tactile_segments(1, seed=34).to(dev)
+    z2 = net.encode_latents(a2, t2)
+    assert not torch.equal(z2, z)
+    assert torch.equal(g_enc(a2, t2), z2)
+    assert torch.equal(g_dec(z2), net.T_DEC(z2))
+    assert torch.equal(g_enc(a, t), z)                       # and back

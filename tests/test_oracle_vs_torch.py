@@ -61,14 +61,21 @@ def test_dac_quantizer_matches_torch(orc):
     sd = synth.quantizer_state(5, n_codebooks=8)
     q = T.ResidualVectorQuantize(n_codebooks=8); q.load_state_dict(sd, strict=True)
     z = torch.randn(2, 1024, 40, generator=torch.Generator().manual_seed(1))
-    zq, codes, lat, cl, cbl = q(z)
+    T.VectorQuantize.margin_log = []
+    try:
+        zq, codes, lat, cl, cbl = q(z)
+        mar = torch.stack([m for m, _ in T.VectorQuantize.margin_log], dim=1)
+        sca = torch.stack([s_ for _, s_ in T.VectorQuantize.margin_log], dim=1)
+    finally:
+        T.VectorQuantize.margin_log = None
     o_zq, o_codes, o_lat, _, _ = orc.dac_quantizer({k: v.numpy() for k, v in sd.items()}, z.numpy())
-    agree = (o_codes == codes.numpy()).mean()
-    assert agree >= 0.97, agree                               # near-ties may flip under a different summation order
-    same_tok = (o_codes == codes.numpy()).all(axis=1)         # [B,T]: tokens whose every stage agrees
-    assert same_tok.mean() > 0.8
-    d = np.abs(o_zq - zq.numpy()).max(axis=1)
-    assert d[same_tok].max() <= 3e-5 * np.abs(zq.numpy()).max()
+    # codes must be EQUAL; a difference is excused only at a near-tie of the torch side's own scores (gi.check_indices)
+    import golden_inputs as gi
+    taint = gi.check_indices(o_codes, codes.numpy(), mar.numpy(), sca.numpy(), "DAC RVQ codes (oracle vs torch)")
+    assert not taint.all()
+    d = np.abs(o_zq - zq.numpy()).max(axis=(1, 2))
+    assert d[~taint].max() <= 3e-5 * np.abs(zq.numpy()).max()
+    assert np.abs(o_lat - lat.numpy())[~taint].max() <= 3e-5 * np.abs(lat.numpy()).max()
     for n_q in (1, 3):
         c2 = q(z, n_q)[1]
         assert c2.shape == (2, n_q, 40)
@@ -83,5 +90,4 @@ def test_proposed_tactile_only_matches_torch(orc):
     t = synth.tactile_segments(1, seed=2, T=320 * 20)
     want = net.encode_latents(None, t, tactile_only=True).numpy()
     got = orc.proposed_encode_latents({k: v.numpy() for k, v in sd.items()}, None, t.numpy(), tactile_only=True)
-    tok_err = np.abs(got - want).max(axis=1) / np.abs(want).max()
-    assert (tok_err > 1e-4).mean() <= 0.1
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()          # every token: no code flipped, latents to round-off
