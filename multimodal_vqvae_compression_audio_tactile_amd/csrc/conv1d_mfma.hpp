@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <type_traits>
 #include "det_math.hpp"
 
 namespace mvq {
@@ -276,8 +277,16 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     const int b_same = b_base + h * D_SAME;
     const int b_cross = b_base + h * D_CROSS;
 
-    // one chunk of MFMAs out of LDS buffer `buf`; operands of k-step s+1 are fetched before the MFMAs of step s
-    auto mfma_chunk = [&](int buf) __attribute__((always_inline)) {
+    // N-subtiles (32 columns each) of this wave that hold at least one real column.  In the last column tile of a row whose
+    // length is not a multiple of BN (T = 600: 88 of 128 columns, T = 3000: 56) the subtiles past the end would only multiply
+    // zeros: a wave skips their MFMAs, which frees its SIMD's matrix pipe for the co-resident blocks' waves.
+    int nt_valid = (a.Ncols - n0 - wn * (NT * 32) + 31) / 32;
+    nt_valid = nt_valid < 0 ? 0 : (nt_valid > NT ? NT : nt_valid);
+
+    // one chunk of MFMAs out of LDS buffer `buf`; operands of k-step s+1 are fetched before the MFMAs of step s.
+    // FULL: every subtile is live (the scheduled fast path); otherwise subtiles j >= nt_valid are left out (wave-uniform).
+    auto mfma_chunk = [&](int buf, auto full_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value;
         const float* wsrc = Ws + buf * C::W_FLOATS + a_base;
         const float* xs_same = Xs + buf * C::X_FLOATS + b_same;
         const float* xs_cross = Xs + buf * C::X_FLOATS + b_cross;
@@ -302,10 +311,13 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
-            // operand reads of step s+1 first, then the MFMAs of step s (keeps a full k-step of latency cover)
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+                    if (FULL || j < nt_valid)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
+            if (FULL) {
+                // operand reads of step s+1 first, then the MFMAs of step s (keeps a full k-step of latency cover)
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+            }
         }
     };
 
@@ -315,15 +327,19 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     __syncthreads();
     // steady state (no conditionals around the staging registers: loads of chunk c+1 stay in flight across the
     // MFMAs of chunk c), last chunk peeled
-    for (int c = 0; c + 1 < n_chunks; ++c) {
-        tile.load_chunk(c + 1, wreg, xv, xs);
-        __builtin_amdgcn_sched_barrier(0);            // keep the loads ABOVE the MFMAs (the scheduler sinks them otherwise)
-        mfma_chunk(c & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        tile.store_chunk(c + 1, (c + 1) & 1, wreg, xv, xs);
-        __syncthreads();
-    }
-    mfma_chunk((n_chunks - 1) & 1);
+    auto k_loop = [&](auto full_c) __attribute__((always_inline)) {
+        for (int c = 0; c + 1 < n_chunks; ++c) {
+            tile.load_chunk(c + 1, wreg, xv, xs);
+            __builtin_amdgcn_sched_barrier(0);        // keep the loads ABOVE the MFMAs (the scheduler sinks them otherwise)
+            mfma_chunk(c & 1, full_c);
+            __builtin_amdgcn_sched_barrier(0);
+            tile.store_chunk(c + 1, (c + 1) & 1, wreg, xv, xs);
+            __syncthreads();
+        }
+        mfma_chunk((n_chunks - 1) & 1, full_c);
+    };
+    if (nt_valid == NT) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
 
     // ---------------------------------------------------------------- fused ResidualUnit tail (FUSE)
     // The block owns ALL channels of its time tile (BM == C), so the 1x1 conv of the ResidualUnit runs here:
@@ -377,7 +393,8 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[grp & 1][g][i], bvv[j], acc[i][j], 0, 0, 0);
+                        if (j < nt_valid)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[grp & 1][g][i], bvv[j], acc[i][j], 0, 0, 0);
             }
         }
         ep_bias = a.bias2;

@@ -167,51 +167,79 @@ __global__ void conv1d_direct_kernel(DirectConvArgs a)
     }
 }
 
-// Cin == 1, stride 1 (encoder input conv): one block row per (batch, output channel), 4 outputs per thread
-// (16-byte stores when rows are aligned), the KS taps + bias live in registers.
+// Cin == 1, stride 1, dil 1 (encoder input conv; the input-gradient of the decoder output conv): a pure streaming WRITE
+// (Cout rows out for one row in).  Each thread owns 4 consecutive output samples and walks CG output channels with the
+// KS + 3 input samples of its window held in registers (fetched once, as three aligned 16-byte loads when the row allows),
+// so the only memory instruction per 16 bytes written is the store itself; the taps / bias / alphas of a channel are
+// block-uniform (scalar loads).  Chain per output: taps ascending from +0.0f, then + bias (the contract).
+constexpr int CIN1_CG = 16;
+
 template <int KS>
 __global__ __launch_bounds__(256) void conv1d_cin1_kernel(DirectConvArgs a)
 {
-    const int co = blockIdx.y, b = blockIdx.z;
+    const int co0 = blockIdx.y * CIN1_CG, b = blockIdx.z;
     const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (t0 >= a.Tout) return;
-    float w[KS];
-#pragma unroll
-    for (int k = 0; k < KS; ++k) w[k] = a.wp[(size_t)k * a.Mpad + co];
-    const float bv = a.bias ? a.bias[co] : 0.0f;
     const float* xr = a.x + (size_t)b * a.Tin;
     float xv[KS + 3];
-#pragma unroll
-    for (int i = 0; i < KS + 3; ++i) {
-        const int g = t0 - a.pad + i * a.dil;            // dil == 1 for this kernel
-        xv[i] = (g >= 0 && g < a.Tin) ? xr[g] : 0.0f;
-    }
-    float al = 0.0f, inv = 0.0f, a2 = 0.0f, i2 = 0.0f, ad = 0.0f, idv = 0.0f;
-    if (a.dsn_src) { ad = a.dsn_alpha[co]; idv = 1.0f / (ad + 1e-9f); }
-    if (a.alpha_out) { al = a.alpha_out[co]; inv = 1.0f / (al + 1e-9f); }
-    if (a.y2) { a2 = a.alpha2[co]; i2 = 1.0f / (a2 + 1e-9f); }
-    const size_t off = ((size_t)b * a.Cout + co) * a.Tout + t0;
-    float o[4], o2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) acc = dfma(w[k], xv[j + k], acc);
-        float v = acc + bv;
-        if (a.dsn_src && t0 + j < a.Tout) v = v * det_dsnake(a.dsn_src[off + j], ad, idv);
-        o2[j] = a.y2 ? det_snake(v, a2, i2) : 0.0f;
-        if (a.alpha_out) v = det_snake(v, al, inv);
-        if (a.act == 1) v = det_tanh(v);
-        o[j] = v;
-    }
-    const bool vec = (t0 + 3 < a.Tout) && ((off & 3) == 0);
-    if (vec) {
-        *reinterpret_cast<float4*>(a.y + off) = make_float4(o[0], o[1], o[2], o[3]);
-        if (a.y2) *reinterpret_cast<float4*>(a.y2 + off) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+    const bool vin = KS == 7 && a.pad == 3 && (a.Tin & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) && t0 + 3 < a.Tin;
+    if (vin) {                                           // window t0-3 .. t0+6 inside the aligned quads t0-4, t0, t0+4
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const v4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const v4 q0 = t0 >= 4 ? *reinterpret_cast<const v4*>(xr + t0 - 4) : z4;
+        const v4 q1 = *reinterpret_cast<const v4*>(xr + t0);
+        const v4 q2 = t0 + 4 < a.Tin ? *reinterpret_cast<const v4*>(xr + t0 + 4) : z4;
+        xv[0] = q0.y; xv[1] = q0.z; xv[2] = q0.w; xv[3] = q1.x; xv[4] = q1.y; xv[5] = q1.z; xv[6] = q1.w;
+        xv[7] = q2.x; xv[8] = q2.y; xv[9] = q2.z;
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (t0 + j < a.Tout) { a.y[off + j] = o[j]; if (a.y2) a.y2[off + j] = o2[j]; }
+        for (int i = 0; i < KS + 3; ++i) {
+            const int g = t0 - a.pad + i;
+            xv[i] = (g >= 0 && g < a.Tin) ? xr[g] : 0.0f;
+        }
+    }
+    const int nco = a.Cout - co0 < CIN1_CG ? a.Cout - co0 : CIN1_CG;
+    for (int c = 0; c < nco; ++c) {
+        const int co = co0 + c;
+        float w[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) w[k] = a.wp[(size_t)k * a.Mpad + co];
+        const float bv = a.bias ? a.bias[co] : 0.0f;
+        float al = 0.0f, inv = 0.0f, a2 = 0.0f, i2 = 0.0f, ad = 0.0f, idv = 0.0f;
+        if (a.dsn_src) { ad = a.dsn_alpha[co]; idv = 1.0f / (ad + 1e-9f); }
+        if (a.alpha_out) { al = a.alpha_out[co]; inv = 1.0f / (al + 1e-9f); }
+        if (a.y2) { a2 = a.alpha2[co]; i2 = 1.0f / (a2 + 1e-9f); }
+        const size_t off = ((size_t)b * a.Cout + co) * a.Tout + t0;
+        const bool vec = (t0 + 3 < a.Tout) && ((off & 3) == 0);
+        float ds[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (a.dsn_src) {
+            if (vec) { const float4 d4 = *reinterpret_cast<const float4*>(a.dsn_src + off); ds[0] = d4.x; ds[1] = d4.y; ds[2] = d4.z; ds[3] = d4.w; }
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (t0 + j < a.Tout) ds[j] = a.dsn_src[off + j];
+            }
+        }
+        float o[4], o2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) acc = dfma(w[k], xv[j + k], acc);
+            float v = acc + bv;
+            if (a.dsn_src) v = v * det_dsnake(ds[j], ad, idv);
+            o2[j] = a.y2 ? det_snake(v, a2, i2) : 0.0f;
+            if (a.alpha_out) v = det_snake(v, al, inv);
+            if (a.act == 1) v = det_tanh(v);
+            o[j] = v;
+        }
+        if (vec) {
+            *reinterpret_cast<float4*>(a.y + off) = make_float4(o[0], o[1], o[2], o[3]);
+            if (a.y2) *reinterpret_cast<float4*>(a.y2 + off) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (t0 + j < a.Tout) { a.y[off + j] = o[j]; if (a.y2) a.y2[off + j] = o2[j]; }
+        }
     }
 }
 
@@ -271,7 +299,7 @@ __global__ __launch_bounds__(256) void conv1d_cout1_kernel(DirectConvArgs a)
 hipError_t launch_conv1d_direct(const DirectConvArgs& a, hipStream_t s)
 {
     if (a.Cin == 1 && a.ks == 7 && a.stride == 1 && a.dil == 1 && !a.alpha_in && !a.residual) {
-        dim3 grid((unsigned)((a.Tout + 1023) / 1024), (unsigned)a.Cout, (unsigned)a.B);
+        dim3 grid((unsigned)((a.Tout + 1023) / 1024), (unsigned)((a.Cout + CIN1_CG - 1) / CIN1_CG), (unsigned)a.B);
         hipLaunchKernelGGL(conv1d_cin1_kernel<7>, grid, dim3(256), 0, s, a);
         return hipGetLastError();
     }

@@ -54,6 +54,24 @@ __device__ __forceinline__ void copy_to_lds_f4(float* dst, const float* __restri
 
 constexpr int RVQ_KH = 256;      // codes resident in LDS at a time
 
+// Staging order of a [kh][dv] slice of float4 code-row pieces.  The LDS images below have a pitch == 1 (mod 32), i.e. element
+// (k, d) sits on bank (k + d) mod 32.  Taking the vectors in row-major order puts 24 consecutive pieces of ONE code on the
+// lanes of a store group: banks k + 4m (+ component) repeat every 8 lanes -> 3-way conflicts on every ds_write_b32.  Instead
+// the 32 lanes of a group take a 4-code x 8-piece patch (k = 4*kq + w/8, m = 8*cb + w%8): banks k + 4m cover all 32, and each
+// code's 8 pieces are still one full 128-byte line of its global row.  Needs dv % 8 == 0 and kh % 4 == 0 (D = 96: dv = 24).
+__device__ __forceinline__ void rvq_stage_map(int i, int dv, bool patch, int& k, int& m)
+{
+    if (patch) {
+        const int p = i >> 5, w = i & 31, nb8 = dv >> 3;
+        const int kq = p / nb8, cb = p - kq * nb8;
+        k = kq * 4 + (w >> 3);
+        m = cb * 8 + (w & 7);
+    } else {
+        k = i / dv;
+        m = i - k * dv;
+    }
+}
+
 // LDS: Et[D][KH+1] | hn[KH] | resT[D][TOKS] | qsT[D][TOKS] | best_s[TOKS] | best_i[TOKS]
 template <int RVQ_TOKS>            // tokens per block: 8 (small batches: more blocks) or 32 (large: 4x less codebook staging)
 __global__ __launch_bounds__(256) void rvq_ema_forward_kernel(
@@ -93,19 +111,24 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_kernel(
                 typedef float v4 __attribute__((ext_vector_type(4)));
                 const int dv = D >> 2;                                  // float4 per code row (D % 4 == 0)
                 const int nvec = kh * dv;
+                const bool patch = (dv & 7) == 0 && (kh & 3) == 0;
                 const float* src = emb + (size_t)k0 * D;
                 for (int base = 0; base < nvec; base += 256 * 8) {
                     v4 r[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int i = base + u * 256 + tid;
-                        r[u] = *reinterpret_cast<const v4*>(src + 4 * (size_t)(i < nvec ? i : nvec - 1));
+                        int k, m;
+                        rvq_stage_map(i < nvec ? i : nvec - 1, dv, patch, k, m);
+                        r[u] = *reinterpret_cast<const v4*>(src + 4 * ((size_t)k * dv + m));
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int i = base + u * 256 + tid;
                         if (i < nvec) {
-                            const int k = i / dv, d4 = (i - k * dv) * 4;
+                            int k, m;
+                            rvq_stage_map(i, dv, patch, k, m);
+                            const int d4 = m * 4;
                             Et[(d4 + 0) * KHP + k] = r[u].x; Et[(d4 + 1) * KHP + k] = r[u].y;
                             Et[(d4 + 2) * KHP + k] = r[u].z; Et[(d4 + 3) * KHP + k] = r[u].w;
                         }
@@ -233,19 +256,24 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_mfma_kernel(
                 typedef float v4 __attribute__((ext_vector_type(4)));
                 const int dv = D >> 2;
                 const int nvec = kh * dv;
+                const bool patch = (dv & 7) == 0;                           // kh is a multiple of 32 here
                 const float* src = emb + (size_t)k0 * D;
                 for (int base = 0; base < nvec; base += 256 * 8) {
                     v4 r[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int i = base + u * 256 + tid;
-                        r[u] = *reinterpret_cast<const v4*>(src + 4 * (size_t)(i < nvec ? i : nvec - 1));
+                        int k, m;
+                        rvq_stage_map(i < nvec ? i : nvec - 1, dv, patch, k, m);
+                        r[u] = *reinterpret_cast<const v4*>(src + 4 * ((size_t)k * dv + m));
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int i = base + u * 256 + tid;
                         if (i < nvec) {
-                            const int k = i / dv, d4 = (i - k * dv) * 4;
+                            int k, m;
+                            rvq_stage_map(i, dv, patch, k, m);
+                            const int d4 = m * 4;
                             float* dst = Es + (size_t)k * DP + d4;
                             dst[0] = r[u].x; dst[1] = r[u].y; dst[2] = r[u].z; dst[3] = r[u].w;
                         }
@@ -425,9 +453,42 @@ hipError_t launch_ema_update(const float* z, const int32_t* idx, float* books, i
 //              (the "blocked" order of the contract, see include/mvq.h), weights staged in LDS per stage
 //   search   : L2-normalised cosine search against the LDS-resident normalised codebook, lane-group arg-max
 //   out_proj : straight-through 8-long chain per owned channel, accumulate + residual update in registers
-//   LDS: cbn[K][Dc] | cn2[K] | w[Dc*C] | part[16][Dc][16] | ze[Dc][16] | pre[Dc][16] | red_s[16][16] | red_i[16][16]
+//   LDS: cbn[K][Dc] | cn2[K] | w[Dc*C + 512] | part[16][Dc][16] (red_s / red_i alias it) | ze[Dc][16] | pre[Dc][16]
+// The stage weights are staged with a per-thread-group skew: the 4 thread groups of a wave read rows that are a multiple of
+// 256 bytes apart in the natural images (in_proj: C/16 floats, out_proj: C/16*Dc floats), i.e. the same banks -- the in_proj
+// image therefore gives every group CPT + 4 floats per row, the out_proj image CPT*Dc + 8 floats per group.
 // ------------------------------------------------------------------------------------------------
 constexpr int DQ_TOK = 16;
+
+// dst[skewed(v)] = src[v] for the n/4 float4 pieces of a stage weight; piece v holds elements 4v .. 4v+3 of the natural image
+//   IN  (in_proj  [Dc][C]):  (d, c)  -> d * (C + 16*4) + (c / CPT) * (CPT + 4) + c % CPT
+//   OUT (out_proj [C][Dc]):  (c, d)  -> (c / CPT) * (CPT*Dc + 8) + (c % CPT) * Dc + d
+template <int CPT, int DC, bool OUT>
+__device__ __forceinline__ void copy_weights_skewed(float* dst, const float* __restrict__ src, int tid)
+{
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    constexpr int C = 16 * CPT;
+    constexpr int nvec = DC * C / 4;
+    for (int base = 0; base < nvec; base += 256 * 8) {
+        v4 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + tid;
+            r[u] = *reinterpret_cast<const v4*>(src + 4 * (size_t)(i < nvec ? i : nvec - 1));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + tid;
+            if (i < nvec) {
+                const int e = 4 * i;
+                int o;
+                if (OUT) { const int g = e / (CPT * DC); o = e + 8 * g; }
+                else { const int d = e / C, c = e - d * C; o = d * (C + 64) + (c / CPT) * (CPT + 4) + (c % CPT); }
+                *reinterpret_cast<v4*>(dst + o) = r[u];
+            }
+        }
+    }
+}
 
 template <int CPT, int DC>    // channels per thread (C = 16*CPT), codebook dimension
 __global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
@@ -441,12 +502,13 @@ __global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* cbn = sm;                                   // [K][Dc]
     float* cn2 = cbn + (size_t)K * Dc;                 // [K]
-    float* wst = cn2 + K;                              // [Dc*C]
-    float* part = wst + (size_t)Dc * C;                // [16][Dc][16]
+    float* wst = cn2 + K;                              // [Dc*C + 512] skewed stage weights (copy_weights_skewed)
+    float* part = wst + (size_t)Dc * C + 512;          // [16][Dc][16]
     float* ze = part + 16 * Dc * DQ_TOK;               // [Dc][16]
     float* pre = ze + Dc * DQ_TOK;                     // [Dc][16]
-    float* red_s = pre + Dc * DQ_TOK;                  // [16][16]
+    float* red_s = part;                               // [16][16]  (part is dead once ze is written: a barrier lies between)
     int* red_i = reinterpret_cast<int*>(red_s + 16 * DQ_TOK);
+    static_assert(Dc * 64 <= 512 && 16 * 8 <= 512 && 16 * Dc * DQ_TOK >= 2 * 16 * DQ_TOK, "skew / alias sizes");
 
     const int tid = threadIdx.x;
     const int tok = tid & 15;
@@ -471,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
         const float* cbs = cb + (size_t)st * K * Dc;
         __syncthreads();                               // previous stage done with cbn / wst
         copy_to_lds_f4(cbn, cbs, K * Dc, tid);
-        copy_to_lds_f4(wst, in_w + (size_t)st * Dc * C, Dc * C, tid);
+        copy_weights_skewed<CPT, DC, false>(wst, in_w + (size_t)st * Dc * C, tid);
         __syncthreads();
         // normalised codebook (in place) + squared norms
         for (int k = tid; k < K; k += 256) {
@@ -485,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
         // in_proj block partials: this thread's channels, every codebook dimension
 #pragma unroll
         for (int d = 0; d < Dc; ++d) {
-            const float* wr = wst + (size_t)d * C + c0;
+            const float* wr = wst + (size_t)d * (C + 64) + grp * (CPT + 4);
             float p = 0.0f;
 #pragma unroll
             for (int j = 0; j < CPT; j += 4) {
@@ -506,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
         }
         __syncthreads();
         // out_proj weights [C][Dc] replace the in_proj weights (every in_proj read is behind the barrier above)
-        copy_to_lds_f4(wst, out_w + (size_t)st * C * Dc, Dc * C, tid);
+        copy_weights_skewed<CPT, DC, true>(wst, out_w + (size_t)st * C * Dc, tid);
         {
             // F.normalize over Dc (every thread of a token computes the same values)
             float ss = 0.0f;
@@ -548,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
             const float* ob = out_b + (size_t)st * C + c0;
 #pragma unroll
             for (int j = 0; j < CPT; ++j) {
-                const float* wr = wst + (size_t)(c0 + j) * Dc;
+                const float* wr = wst + grp * (CPT * Dc + 8) + j * Dc;
                 float a = 0.0f;
 #pragma unroll
                 for (int d = 0; d < Dc; ++d) a = dfma(wr[d], pv[d], a);
@@ -571,7 +633,7 @@ static hipError_t launch_dac_rvq_t(const float* z, const float* in_w, const floa
 {
     constexpr int C = 16 * CPT;
     const int N = B * T;
-    const size_t lds = ((size_t)K * DC + K + (size_t)DC * C + 16 * (size_t)DC * DQ_TOK + 2 * (size_t)DC * DQ_TOK + 2 * 16 * DQ_TOK) * sizeof(float);
+    const size_t lds = ((size_t)K * DC + K + (size_t)DC * C + 512 + 16 * (size_t)DC * DQ_TOK + 2 * (size_t)DC * DQ_TOK) * sizeof(float);
     auto kern = dac_rvq_kernel<CPT, DC>;
     static bool attr = false;
     if (!attr) {
