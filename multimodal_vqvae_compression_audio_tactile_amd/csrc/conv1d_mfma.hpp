@@ -20,7 +20,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-#include <type_traits>
 #include "det_math.hpp"
 
 namespace mvq {
@@ -41,7 +40,9 @@ struct ConvArgs {
     int Mpad;               // padded M (row pitch of wp)
     int Mrows;              // valid GEMM rows (Cout, or Cout*S for UPS)
     int Ncols;              // GEMM columns per batch element (Tout, or Tin+1 for UPS)
-    int n_tiles;            // ceil(Ncols / BN)
+    int n_tiles;            // column tiles per batch element of THIS launch: ceil((Ncols - n_base) / BN), at most n_tiles_max
+    int n_base;             // first GEMM column of this launch (0 unless the row is split into a wide-tile launch and a tail launch)
+    int n_tiles_max;        // > 0: this launch covers only that many column tiles (the rest belongs to the tail launch)
     int row_fast;           // 0: grid (column tiles, row tiles).  R > 0: 1-D grid, XCD-aware: the R row tiles of a column
                             // tile are consecutive on ONE XCD (workgroup id mod 8), so the x tile is fetched into that L2 once
     int act;
@@ -232,7 +233,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     }
     const int b = bx / a.n_tiles;
     const int tile_n = bx - b * a.n_tiles;
-    const int n0 = tile_n * C::BN;
+    const int n0 = a.n_base + tile_n * C::BN;
     const int m0 = by * C::BM;
     const int t_in0 = n0 * STRIDE - a.pad;           // input sample of tile column 0
     const int g_al = t_in0 & ~3;                     // 16-byte aligned start (floor, also for negatives)
@@ -277,16 +278,10 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     const int b_same = b_base + h * D_SAME;
     const int b_cross = b_base + h * D_CROSS;
 
-    // N-subtiles (32 columns each) of this wave that hold at least one real column.  In the last column tile of a row whose
-    // length is not a multiple of BN (T = 600: 88 of 128 columns, T = 3000: 56) the subtiles past the end would only multiply
-    // zeros: a wave skips their MFMAs, which frees its SIMD's matrix pipe for the co-resident blocks' waves.
-    int nt_valid = (a.Ncols - n0 - wn * (NT * 32) + 31) / 32;
-    nt_valid = nt_valid < 0 ? 0 : (nt_valid > NT ? NT : nt_valid);
-
-    // one chunk of MFMAs out of LDS buffer `buf`; operands of k-step s+1 are fetched before the MFMAs of step s.
-    // FULL: every subtile is live (the scheduled fast path); otherwise subtiles j >= nt_valid are left out (wave-uniform).
-    auto mfma_chunk = [&](int buf, auto full_c) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full_c)::value;
+    // one chunk of MFMAs out of LDS buffer `buf`; operands of k-step s+1 are fetched before the MFMAs of step s
+    // (Skipping the MFMAs of column subtiles that lie past the end of the row was measured: +0.3 % -- the block lasts as long
+    // as its busiest wave.  Rows with a mostly empty last tile are split into two launches instead: conv_tail_width.)
+    auto mfma_chunk = [&](int buf) __attribute__((always_inline)) {
         const float* wsrc = Ws + buf * C::W_FLOATS + a_base;
         const float* xs_same = Xs + buf * C::X_FLOATS + b_same;
         const float* xs_cross = Xs + buf * C::X_FLOATS + b_cross;
@@ -311,13 +306,10 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    if (FULL || j < nt_valid)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
-            if (FULL) {
-                // operand reads of step s+1 first, then the MFMAs of step s (keeps a full k-step of latency cover)
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
-            }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
+            // operand reads of step s+1 first, then the MFMAs of step s (keeps a full k-step of latency cover)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
         }
     };
 
@@ -327,19 +319,15 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     __syncthreads();
     // steady state (no conditionals around the staging registers: loads of chunk c+1 stay in flight across the
     // MFMAs of chunk c), last chunk peeled
-    auto k_loop = [&](auto full_c) __attribute__((always_inline)) {
-        for (int c = 0; c + 1 < n_chunks; ++c) {
-            tile.load_chunk(c + 1, wreg, xv, xs);
-            __builtin_amdgcn_sched_barrier(0);        // keep the loads ABOVE the MFMAs (the scheduler sinks them otherwise)
-            mfma_chunk(c & 1, full_c);
-            __builtin_amdgcn_sched_barrier(0);
-            tile.store_chunk(c + 1, (c + 1) & 1, wreg, xv, xs);
-            __syncthreads();
-        }
-        mfma_chunk((n_chunks - 1) & 1, full_c);
-    };
-    if (nt_valid == NT) k_loop(std::true_type{});
-    else k_loop(std::false_type{});
+    for (int c = 0; c + 1 < n_chunks; ++c) {
+        tile.load_chunk(c + 1, wreg, xv, xs);
+        __builtin_amdgcn_sched_barrier(0);            // keep the loads ABOVE the MFMAs (the scheduler sinks them otherwise)
+        mfma_chunk(c & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        tile.store_chunk(c + 1, (c + 1) & 1, wreg, xv, xs);
+        __syncthreads();
+    }
+    mfma_chunk((n_chunks - 1) & 1);
 
     // ---------------------------------------------------------------- fused ResidualUnit tail (FUSE)
     // The block owns ALL channels of its time tile (BM == C), so the 1x1 conv of the ResidualUnit runs here:
@@ -393,8 +381,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        if (j < nt_valid)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[grp & 1][g][i], bvv[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[grp & 1][g][i], bvv[j], acc[i][j], 0, 0, 0);
             }
         }
         ep_bias = a.bias2;
@@ -613,7 +600,8 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
                  WAVES_M, WAVES_N, UPS);
         return hipSuccess;
     }
-    a.n_tiles = (a.Ncols + C::BN - 1) / C::BN;
+    a.n_tiles = (a.Ncols - a.n_base + C::BN - 1) / C::BN;
+    if (a.n_tiles_max > 0 && a.n_tiles > a.n_tiles_max) a.n_tiles = a.n_tiles_max;
     a.vec4 = (a.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     a.ovec4 = (a.Tout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
               (!a.residual || (reinterpret_cast<uintptr_t>(a.residual) & 15) == 0) &&
@@ -653,6 +641,20 @@ inline int conv_tile_bm(int mrows)
     return mrows > 96 ? 128 : (mrows > 64 ? 96 : 64);
 }
 inline int conv_mpad(int mrows) { const int bm = conv_tile_bm(mrows); return (mrows + bm - 1) / bm * bm; }
+
+// Column split.  A row whose length is not a multiple of the 128-column tile ends in a tile that is mostly padding (T = 600:
+// 88 of 128 columns, T = 3000: 56).  Skipping the dead MFMAs inside that tile buys nothing -- the block still lasts as long as
+// its busiest wave -- so the row is split instead: the full tiles go out as one launch, the remainder as a second launch of
+// a narrower tile of the SAME kernel family (128 x 96 or 128 x 64: every wave of the block again has live columns only).
+// Returns the tail tile width (96 / 64) or 0 when the row is not split (no remainder, remainder > 96, or a saving < 1 %).
+inline int conv_tail_width(const ConvArgs& a)
+{
+    if (a.n_base != 0 || a.n_tiles_max != 0) return 0;          // already one half of a split
+    const int full = a.Ncols / 128, rem = a.Ncols % 128;
+    if (full == 0 || rem == 0 || rem > 96) return 0;
+    const int w = rem <= 64 ? 64 : 96;
+    return (128 - w) * 100 >= (full + 1) * 128 ? w : 0;
+}
 
 // Latency regime: when the 128-row tiling would leave most of the 256 CUs idle (small batch x short sequences), the
 // same kernel runs with 64 x 64 tiles -- 4x the blocks, each walking the same K chain, so results are unchanged.

@@ -5,6 +5,18 @@ hipError_t launch_conv_k1k3(const ConvArgs& a, int ks, int bm, hipStream_t s)
 {
     if (ks == 1) {
         if (bm != 96 && conv_prefer_small_tiles(a)) return launch_conv1d_mfma<1, 1, 1, 32, 1, 1, 2, 2, 0>(a, s);
+        if (bm == 128) {
+            const int tail = a.name_out ? 0 : conv_tail_width(a);
+            if (tail) {                                              // full 128-column tiles, then the narrow tail tile
+                ConvArgs m = a, t = a;
+                m.n_tiles_max = a.Ncols / 128;
+                t.n_base = m.n_tiles_max * 128;
+                hipError_t e = launch_conv1d_mfma<1, 1, 1, 16, 2, 2, 2, 2, 0>(m, s);
+                if (e != hipSuccess) return e;
+                return tail == 96 ? launch_conv1d_mfma<1, 1, 1, 16, 1, 3, 4, 1, 0>(t, s)
+                                  : launch_conv1d_mfma<1, 1, 1, 16, 2, 1, 2, 2, 0>(t, s);
+            }
+        }
         switch (bm) {
             case 128: return launch_conv1d_mfma<1, 1, 1, 16, 2, 2, 2, 2, 0>(a, s);
             case 96:  // 16-channel stages: 3 blocks per CU (+11 % on the C = 192 layer); a grid that cannot fill the CUs anyway

@@ -61,6 +61,11 @@ CONV_CASES = [
     (3, 64, 20000, 128, 4, 2, 1, 1, False, False, False, False),  # strided s=2
     (4, 256, 9000, 512, 10, 5, 1, 3, False, False, False, False), # strided s=5
     (8, 1024, 75, 1024, 3, 1, 1, 1, False, False, False, False),  # k3 at the latent rate, 128x96 tile
+    # column split (conv_tail_width): T = 600 -> four 128-column tiles + one 96-column tail launch; T = 3000-ish -> 64-column tail
+    (16, 256, 600, 256, 7, 1, 9, 27, False, False, True, False),
+    (8, 512, 600, 512, 7, 1, 1, 3, True, True, False, False),
+    (6, 768, 600, 768, 1, 1, 1, 0, False, True, True, False),
+    (4, 256, 3000, 256, 7, 1, 3, 9, False, True, True, False),
 ]
 
 
