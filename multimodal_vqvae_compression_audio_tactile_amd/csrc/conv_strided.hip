@@ -16,6 +16,16 @@ hipError_t launch_conv_strided(const ConvArgs& a, int stride, int bm, hipStream_
             case 8: return launch_conv1d_mfma<16, 8, 1, 4, 1, 1, 2, 2, 0>(a, s);
         }
     }
+    const int tail = a.name_out ? 0 : conv_tail_width(a);
+    if (tail && (stride == 4 || stride == 5)) {                     // column split (conv1d_mfma.hpp, conv_tail_width)
+        ConvArgs m = a, t = a;
+        m.n_tiles_max = a.Ncols / 128;
+        t.n_base = m.n_tiles_max * 128;
+        hipError_t e = stride == 4 ? launch_conv1d_mfma<8, 4, 1, 4, 2, 2, 2, 2, 0>(m, s) : launch_conv1d_mfma<10, 5, 1, 2, 2, 2, 2, 2, 0>(m, s);
+        if (e != hipSuccess) return e;
+        if (stride == 4) return tail == 96 ? launch_conv1d_mfma<8, 4, 1, 4, 1, 3, 4, 1, 0>(t, s) : launch_conv1d_mfma<8, 4, 1, 4, 2, 1, 2, 2, 0>(t, s);
+        return tail == 96 ? launch_conv1d_mfma<10, 5, 1, 2, 1, 3, 4, 1, 0>(t, s) : launch_conv1d_mfma<10, 5, 1, 2, 2, 1, 2, 2, 0>(t, s);
+    }
     switch (stride) {
         case 2: return launch_conv1d_mfma<4, 2, 1, 8, 2, 2, 2, 2, 0>(a, s);
         case 4: return launch_conv1d_mfma<8, 4, 1, 4, 2, 2, 2, 2, 0>(a, s);
