@@ -19,7 +19,8 @@ data-path collective ("weak" scaling: per-GPU batch fixed).  Rank 0 prints ONE J
 Extra objects on the line:
   roofline     -- the dominant kernel (largest share of device time among the conv / residual-unit kernel instantiations): algorithmic
                   FLOPs per launch / its average duration measured with HIP events on the launch stream during the
-                  timed steps, against the fp32 MFMA peak (157.3 TFLOP/s).
+                  timed steps (one event pair per kernel launch, recorded inside the library: mvq_profile_begin/_end),
+                  against the fp32 MFMA peak (157.3 TFLOP/s).
   cpu_baseline -- the torch-CPU restatement of the same path (oracle/dac24_torch.py, "port") timed on this node's
                   host cores on a bounded sample, rank 0 / N=1 only.
 """
@@ -67,60 +68,17 @@ def parse():
 
 
 class KernelEvents:
-    """Per-launch HIP event pairs on the launch stream (torch's current stream IS the stream ops.* launch on)."""
+    """Per-launch HIP event pairs on the launch stream, recorded INSIDE the library around every conv / residual-unit kernel
+    launch (mvq_profile_begin / mvq_profile_end, include/mvq.h) together with the launch's algorithmic FLOPs -- zero-padded
+    rows and tail tiles not counted.  One entry per kernel instantiation, named as rocprofv3 names it, so `seconds /
+    launches` here is the same quantity as that kernel's average duration in `rocprofv3 --kernel-trace --stats`."""
 
-    def __init__(self):
-        self.records = []
-
-    def wrap(self, ops):
-        orig_conv, orig_tr, orig_ru = ops.conv1d, ops.conv_transpose1d, ops.residual_unit_fused
-        rec = self.records
-
-        # algorithmic flops count TRUE columns only (zero-padded rows: tvalid / tout_rows, include/mvq.h)
-        def residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, alpha_dual=None, tvalid=0):
-            B, c, t = x.shape
-            t = tvalid or t
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            y = orig_ru(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next, alpha_dual, tvalid)
-            e1.record()
-            rec.append((ops.residual_unit_kernel_name(c, dil), 2.0 * c * c * 8 * t * B, e0, e1))
-            return y
-
-        def conv1d(x, wp, cout, ks, bias=None, stride=1, dil=1, pad=0, **kw):
-            B, cin, tin = x.shape
-            tout = kw.get("tvalid") or ops.conv1d_out_len(tin, ks, stride, dil, pad)
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            y = orig_conv(x, wp, cout, ks, bias=bias, stride=stride, dil=dil, pad=pad, **kw)
-            e1.record()
-            rec.append((ops.conv_kernel_name(cin, cout, ks, stride, dil, tin=tin, batch=B), 2.0 * cin * cout * ks * tout * B, e0, e1))
-            return y
-
-        def conv_transpose1d(x, wp, cout, stride, pad, **kw):
-            B, cin, tin = x.shape
-            t_out = kw.get("tvalid") or kw.get("tout_rows") or ((tin - 1) * stride - 2 * pad + 2 * stride)
-            tin_true = (t_out + 2 * pad - 2 * stride) // stride + 1
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            y = orig_tr(x, wp, cout, stride, pad, **kw)
-            e1.record()
-            rec.append((ops.conv_kernel_name(cin, cout, 2 * stride, stride, 1, transposed=True, tin=tin, batch=B),
-                        2.0 * cin * cout * 2 * stride * tin_true * B, e0, e1))
-            return y
-
-        ops.conv1d, ops.conv_transpose1d, ops.residual_unit_fused = conv1d, conv_transpose1d, residual_unit_fused
-        self._restore = lambda: (setattr(ops, "conv1d", orig_conv), setattr(ops, "conv_transpose1d", orig_tr),
-                                 setattr(ops, "residual_unit_fused", orig_ru))
+    def __init__(self, ops):
+        self.ops = ops
+        ops.profile_begin()
 
     def summary(self):
-        tot = defaultdict(lambda: [0.0, 0.0, 0])
-        for name, flops, e0, e1 in self.records:
-            t = tot[name]
-            t[0] += e0.elapsed_time(e1) * 1e-3
-            t[1] += flops
-            t[2] += 1
-        return {k: {"seconds": v[0], "flops": v[1], "launches": v[2]} for k, v in tot.items()}
+        return self.ops.profile_end()
 
 
 def host_cores() -> int:
@@ -371,8 +329,8 @@ def main():
     torch.cuda.synchronize()
 
     kev = None
-    if not args.no_kernel_events and not train:           # the train step has ~600 small launches: the per-launch host cost
-        kev = KernelEvents(); kev.wrap(ops)               # of the event wrappers would be what gets measured
+    if not args.no_kernel_events and not train:           # (the train step is reported without the per-kernel table)
+        kev = KernelEvents(ops)
 
     barrier()
     torch.cuda.synchronize()
@@ -382,7 +340,6 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if kev: kev._restore()
 
     if dist:
         tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)

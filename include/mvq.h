@@ -10,7 +10,7 @@
  * stream).  Inputs are borrowed and never written; outputs must be caller-allocated.
  * Every function returns 0 on success or a negative MVQ_E* code; mvq_last_error() gives the text.
  * No function allocates, frees or synchronises (safe to capture into a hipGraph), except
- * mvq_device_query().
+ * mvq_device_query() and the mvq_profile_* pair.
  *
  * Arithmetic contract: every dot product is one fp32 fma chain in the order "input channel ascending,
  * then tap ascending" starting from +0.0f, followed by  + bias, + residual, snake, tanh  (each optional).
@@ -38,6 +38,21 @@ extern "C" {
 
 int mvq_abi_version(void);
 const char* mvq_last_error(void);
+
+/* Per-launch HIP-event profiler (measurement aid of bench.py; no reference counterpart).  Between mvq_profile_begin() and
+ * mvq_profile_end() every conv / residual-unit kernel launch of the library is bracketed by a HIP event pair recorded on
+ * the stream it is launched on, together with the launch's ALGORITHMIC FLOPs (2 * Cin * ks * valid rows * valid columns *
+ * batch: zero-padded rows and tail tiles are not counted).  mvq_profile_end() waits for the events (it synchronises) and
+ * returns one entry per kernel instantiation -- the name is the one rocprofv3 prints -- with the summed duration, FLOPs and
+ * launch count.  Not capturable into a hipGraph while enabled. */
+typedef struct mvq_profile_entry {
+    char kernel[96];
+    double seconds;
+    double flops;
+    int launches;
+} mvq_profile_entry;
+int mvq_profile_begin(void);
+int mvq_profile_end(mvq_profile_entry* out, int max_entries, int* n_entries);
 /* fills cu_count / lds_bytes / gcn arch name ("gfx950...") of the current device; synchronous. */
 int mvq_device_query(int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len);
 

@@ -14,8 +14,15 @@ _PKG = Path(__file__).resolve().parent
 SO_PATH = _PKG / "libmvq_hip.so"
 _lib = None
 
+class ProfileEntry(ctypes.Structure):
+    """mvq_profile_entry (include/mvq.h)."""
+    _fields_ = [("kernel", ctypes.c_char * 96), ("seconds", ctypes.c_double), ("flops", ctypes.c_double), ("launches", c_int)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
+    "mvq_profile_begin": (c_int, []),
+    "mvq_profile_end": (c_int, [ctypes.POINTER(ProfileEntry), c_int, ctypes.POINTER(c_int)]),
     "mvq_abi_version": (c_int, []),
     "mvq_last_error": (c_char_p, []),
     "mvq_device_query": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_char_p, c_int]),

@@ -8,6 +8,41 @@
 #include "conv_dispatch.hpp"
 #include "kernels_small.hpp"
 
+#include <map>
+#include <string>
+#include <vector>
+
+namespace mvq {
+// ---- per-launch HIP-event profiler ------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { std::string name; double flops; hipEvent_t e0, e1; };
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_pool;          // events are reused between sessions
+bool g_prof_on = false;
+hipEvent_t prof_event()
+{
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+bool prof_enabled() { return g_prof_on; }
+int prof_begin(const char* kernel_name, double flops, hipStream_t s)
+{
+    if (!g_prof_on) return -1;
+    ProfRec r{kernel_name, flops, prof_event(), prof_event()};
+    if (!r.e0 || !r.e1) return -1;
+    (void)hipEventRecord(r.e0, s);
+    g_prof.push_back(r);
+    return (int)g_prof.size() - 1;
+}
+void prof_end(int idx, hipStream_t s)
+{
+    if (idx >= 0 && idx < (int)g_prof.size()) (void)hipEventRecord(g_prof[idx].e1, s);
+}
+}  // namespace mvq
+
 namespace {
 thread_local char g_err[512] = "";
 
@@ -29,6 +64,46 @@ inline int conv_out_len(int tin, int ks, int stride, int dil, int pad)
 }  // namespace
 
 extern "C" {
+
+int mvq_profile_begin(void)
+{
+    for (auto& r : mvq::g_prof) { mvq::g_prof_pool.push_back(r.e0); mvq::g_prof_pool.push_back(r.e1); }
+    mvq::g_prof.clear();
+    mvq::g_prof_on = true;
+    return MVQ_OK;
+}
+
+int mvq_profile_end(mvq_profile_entry* out, int max_entries, int* n_entries)
+{
+    mvq::g_prof_on = false;
+    if (!n_entries || (max_entries > 0 && !out)) return fail(MVQ_EINVAL, "profile_end: null argument");
+    std::map<std::string, mvq_profile_entry> agg;
+    for (auto& r : mvq::g_prof) {
+        hipError_t e = hipEventSynchronize(r.e1);
+        if (e != hipSuccess) return hipfail(e, "profile_end: hipEventSynchronize");
+        float ms = 0.0f;
+        e = hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (e != hipSuccess) return hipfail(e, "profile_end: hipEventElapsedTime");
+        auto it = agg.find(r.name);
+        if (it == agg.end()) {
+            mvq_profile_entry z{};
+            snprintf(z.kernel, sizeof(z.kernel), "%s", r.name.c_str());
+            it = agg.emplace(r.name, z).first;
+        }
+        it->second.seconds += 1e-3 * (double)ms;
+        it->second.flops += r.flops;
+        it->second.launches += 1;
+    }
+    for (auto& r : mvq::g_prof) { mvq::g_prof_pool.push_back(r.e0); mvq::g_prof_pool.push_back(r.e1); }
+    mvq::g_prof.clear();
+    *n_entries = (int)agg.size();
+    int i = 0;
+    for (auto& kv : agg) {
+        if (i >= max_entries) break;
+        out[i++] = kv.second;
+    }
+    return MVQ_OK;
+}
 
 int mvq_abi_version(void) { return 1; }
 const char* mvq_last_error(void) { return g_err; }

@@ -24,6 +24,12 @@
 
 namespace mvq {
 
+// Per-launch HIP-event profiler (api.hip; mvq_profile_begin / mvq_profile_end in include/mvq.h).  Off: prof_begin returns -1
+// and nothing is recorded.  On: one event pair per kernel launch on the launch stream, with the launch's algorithmic FLOPs.
+int prof_begin(const char* kernel_name, double flops, hipStream_t s);
+void prof_end(int idx, hipStream_t s);
+bool prof_enabled();
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -585,7 +591,15 @@ inline hipError_t launch_residual_unit(const ConvArgs& a_in, hipStream_t stream)
         attr_set = true;
     }
     dim3 grid((unsigned)(a.n_tiles * a.B), 1);
+    int pi = -1;
+    if (prof_enabled()) {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "residual_unit_kernel<%d, %d, %d, %d, %d, %d>", DIL, CK, MT, NT, WAVES_M, WAVES_N);
+        const int cols = a.tvalid > 0 ? a.tvalid : a.Ncols;
+        pi = prof_begin(nm, 2.0 * a.Cin * a.Cout * 8.0 * cols * a.B, stream);
+    }
     hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), lds, stream, a);
+    prof_end(pi, stream);
     return hipGetLastError();
 }
 
@@ -628,7 +642,22 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
         a.row_fast = (int)R;
         grid = dim3(((gx + 7) / 8) * 8 * R, 1);
     }
+    int pi = -1;
+    if (prof_enabled()) {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "conv1d_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS);
+        // algorithmic FLOPs of THIS launch: its share of the true GEMM columns (zero-padded tails and, for the polyphase
+        // ConvTranspose1d, the extra boundary column do not count), every valid row, the whole K
+        int last = a.n_base + a.n_tiles * C::BN;
+        int lim = a.Ncols;
+        if (UPS > 0) lim = a.Ncols - 1;                               // Ncols = Tin + 1 GEMM columns for Tin input samples
+        else if (a.tvalid > 0) lim = a.tvalid;
+        if (last > lim) last = lim;
+        const int cols = last > a.n_base ? last - a.n_base : 0;
+        pi = prof_begin(nm, 2.0 * a.Cin * KS * a.Mrows * (double)cols * a.B, stream);
+    }
     hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), lds, stream, a);
+    prof_end(pi, stream);
     return hipGetLastError();
 }
 

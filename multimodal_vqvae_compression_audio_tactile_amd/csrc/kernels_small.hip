@@ -300,12 +300,16 @@ hipError_t launch_conv1d_direct(const DirectConvArgs& a, hipStream_t s)
 {
     if (a.Cin == 1 && a.ks == 7 && a.stride == 1 && a.dil == 1 && !a.alpha_in && !a.residual) {
         dim3 grid((unsigned)((a.Tout + 1023) / 1024), (unsigned)((a.Cout + CIN1_CG - 1) / CIN1_CG), (unsigned)a.B);
+        const int pi = prof_enabled() ? prof_begin("conv1d_cin1_kernel<7>", 2.0 * 7 * a.Cout * (double)a.Tout * a.B, s) : -1;
         hipLaunchKernelGGL(conv1d_cin1_kernel<7>, grid, dim3(256), 0, s, a);
+        prof_end(pi, s);
         return hipGetLastError();
     }
     if (a.Cout == 1 && a.ks == 7 && a.stride == 1 && a.dil == 1 && !a.alpha_in && !a.y2 && !a.dsn_src && a.Cin * 7 * 4 <= 48 * 1024) {
         dim3 grid((unsigned)((a.Tout + 1023) / 1024), (unsigned)a.B);
+        const int pi = prof_enabled() ? prof_begin("conv1d_cout1_kernel<7>", 2.0 * 7 * a.Cin * (double)a.Tout * a.B, s) : -1;
         hipLaunchKernelGGL(conv1d_cout1_kernel<7>, grid, dim3(256), (size_t)a.Cin * 7 * sizeof(float), s, a);
+        prof_end(pi, s);
         return hipGetLastError();
     }
     const size_t total = (size_t)a.B * a.Cout * a.Tout;

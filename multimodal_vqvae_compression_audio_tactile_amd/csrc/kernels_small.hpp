@@ -6,6 +6,10 @@
 
 namespace mvq {
 
+int prof_begin(const char* kernel_name, double flops, hipStream_t s);     // api.hip (see conv1d_mfma.hpp)
+void prof_end(int idx, hipStream_t s);
+bool prof_enabled();
+
 struct DirectConvArgs {
     const float* x; const float* wp; const float* bias; const float* alpha_in; const float* residual;
     const float* alpha_out; float* y;

@@ -98,6 +98,21 @@ def conv1d(x, wp, cout, ks, bias=None, stride=1, dil=1, pad=0, alpha_in=None, re
     return out if alpha_dual is None else (out, y2)
 
 
+def profile_begin() -> None:
+    """Start bracketing every conv / residual-unit kernel launch with HIP events on its launch stream (include/mvq.h)."""
+    check(_lib.lib().mvq_profile_begin(), "mvq_profile_begin")
+
+
+def profile_end() -> dict:
+    """Stop and collect: {kernel instantiation name: {"seconds", "flops", "launches"}} (synchronises)."""
+    import ctypes
+    buf = (_lib.ProfileEntry * 256)()
+    n = ctypes.c_int(0)
+    check(_lib.lib().mvq_profile_end(buf, 256, ctypes.byref(n)), "mvq_profile_end")
+    return {buf[i].kernel.decode(): {"seconds": buf[i].seconds, "flops": buf[i].flops, "launches": buf[i].launches}
+            for i in range(min(n.value, 256))}
+
+
 def residual_unit_kernel_name(c, dil) -> str:
     import ctypes
     buf = ctypes.create_string_buffer(160)

@@ -292,9 +292,9 @@ class ProposedEval(nn.Module):
         for s in range(0, Tlat, self.chunk):
             e = min(Tlat, s + self.chunk)
             if tactile_only:
-                z_pred = torch.zeros(B, C, e - s)
+                z_pred = zt.new_zeros(B, C, e - s)
             else:
-                zt_prev = torch.zeros(B, C, e - s)
+                zt_prev = zt.new_zeros(B, C, e - s)
                 if s == 0:
                     zt_prev[..., 1:] = z_run[..., s:e - 1]
                 else:
@@ -324,7 +324,7 @@ class ProposedEval(nn.Module):
         rD_all = []
         for s in range(0, Tlat, self.chunk):
             e = min(Tlat, s + self.chunk)
-            zt_prev = torch.zeros(B, C, e - s)
+            zt_prev = zt.new_zeros(B, C, e - s)
             if s == 0:
                 zt_prev[..., 1:] = z_run[..., s:e - 1]
             else:

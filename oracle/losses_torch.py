@@ -50,8 +50,9 @@ class MelScale(torch.nn.Module):
 
 
 def stft_mag(x, n_fft, hop, win, eps):
-    window = torch.hann_window(win, dtype=torch.float32)
-    spec = torch.stft(x.to(torch.float32), n_fft=n_fft, hop_length=hop, win_length=win, window=window, center=True,
+    dt = torch.float64 if x.dtype == torch.float64 else torch.float32      # float64 in: the exact-value yardstick (fixture G7 "f64.*")
+    window = torch.hann_window(win, dtype=dt)
+    spec = torch.stft(x.to(dt), n_fft=n_fft, hop_length=hop, win_length=win, window=window, center=True,
                       pad_mode="reflect", return_complex=True)
     return spec.abs().clamp_min(eps)
 
@@ -75,7 +76,7 @@ def mrstft(x, y, ffts=(256, 512, 1024), hops=(64, 128, 256), wins=(256, 512, 102
 
 def mel_log(x_1T, fb, n_fft=512, hop=128, eps=1e-7):
     mag = stft_mag(x_1T[:, 0, :], n_fft, hop, n_fft, eps)
-    M = torch.matmul(mag.transpose(-1, -2), fb).transpose(-1, -2)
+    M = torch.matmul(mag.transpose(-1, -2), fb.to(mag.dtype)).transpose(-1, -2)
     den = M.amax(dim=(1, 2), keepdim=True).clamp_min(eps)
     return (M / den + eps).log()
 

@@ -202,6 +202,28 @@ def main():
             g7[f"norm.{name}"] = np.array(float(p_.grad.norm()), np.float64)
             g7[f"sub.{name}"] = p_.grad.reshape(-1)[::gi.GRAD_STRIDE].numpy().copy()
     assert all(p_.grad is None for n_, p_ in net.named_parameters() if n_.split(".")[0] in ("A_ENC", "A_QUANT", "T_ENC", "T_DEC"))
+    # the exact-value yardstick for the tolerances: the same step in float64 (torch restatement of model + losses; the
+    # reference's own loss classes cast to float32 internally, so they cannot be run in double).  Same discrete path: the
+    # float64 run must pick the same codes as the float32 reference, otherwise it is a different function.
+    with torch.enable_grad():
+        n64 = T.ProposedEval(rvq_books=books, rvq_embed=K)
+        n64.load_state_dict(sdm, strict=True)
+        n64 = n64.double().eval()
+        for m_ in (n64.A_ENC, n64.A_QUANT, n64.T_ENC, n64.T_DEC):
+            for p_ in m_.parameters():
+                p_.requires_grad_(False)
+        o64 = n64.forward_step(a.double(), t.double())
+        assert (o64["r_tokens"] - out["r_tokens"].double()).abs().max() < 1e-4 * out["r_tokens"].abs().max()
+        assert (o64["y_hat"] - y.detach().double()).abs().max() < 1e-4                     # same codes, same waveform
+        y64 = o64["y_hat"]; y64.retain_grad()
+        tot64, (l1_64, st_64, me_64) = LT.total_loss(y64, o64["tgt"])
+        tot64.backward()
+    g7["f64.losses"] = np.array([float(l1_64), float(st_64), float(me_64), float(tot64)], np.float64)
+    g7["f64.dy"] = y64.grad.numpy()
+    for name, p_ in n64.named_parameters():
+        if p_.requires_grad and not name.startswith("vq.books"):
+            g7[f"f64.norm.{name}"] = np.array(float(p_.grad.norm()), np.float64)
+            g7[f"f64.sub.{name}"] = p_.grad.reshape(-1)[::gi.GRAD_STRIDE].numpy().copy()
     np.savez_compressed(OUT / "g7_train_step.npz", **g7)
     # ---- G8: stsim_batch from the reference function
     e5.torchaudio.transforms.MelScale = LT.MelScale

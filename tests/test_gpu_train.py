@@ -188,20 +188,34 @@ def test_training_step_matches_reference_fixture(dev):
     total.backward()
     assert rel(out["r_tokens"], torch.from_numpy(G7["r_tokens"])) < 1e-5
     assert rel(out["y_hat"], torch.from_numpy(G7["y_hat"])) < 1e-5
-    got = [float(crit.parts[k]) for k in ("l1", "stft", "mel")] + [float(total)]
-    assert np.allclose(got, G7["losses"], rtol=2e-3), (got, G7["losses"])
-    n, worst = 0, 0.0
+    # Tolerances are set by a yardstick, not by hand: the fixture also holds the SAME step evaluated in float64 ("f64.*",
+    # same codes).  The reference's own float32 classes are err_ref away from that exact value (mel-cosine 9e-4, sampled
+    # gradients up to 1.3e-3: the fixture's brick-wall-filtered target puts the upper mel bands below the float32 rounding
+    # floor); the HIP path has to be as close to the exact value as the reference is (factor 1.5 + a float32 floor), and
+    # of course close to the reference itself.
+    got = np.array([float(crit.parts[k]) for k in ("l1", "stft", "mel")] + [float(total)])
+    exact, ref = G7["f64.losses"], G7["losses"]
+    err_hip, err_ref = np.abs(got - exact) / exact, np.abs(ref - exact) / exact
+    print("loss rel. error vs float64  HIP:", err_hip, " reference fp32:", err_ref)
+    assert np.all(err_hip <= np.maximum(1.5 * err_ref, 2e-6)), (got, ref, exact)
+    assert np.allclose(got, ref, rtol=2e-3)
+    n, worst_hip, worst_ref, worst_pair = 0, 0.0, 0.0, 0.0
     for name, p in net.named_parameters():
         if f"norm.{name}" not in G7.files:
             assert p.grad is None, name
             continue
-        want_n = float(G7[f"norm.{name}"])
-        assert abs(float(p.grad.norm()) - want_n) <= 2e-3 * want_n, name
-        sub, want = p.grad.reshape(-1)[::gi.GRAD_STRIDE].cpu(), torch.from_numpy(G7[f"sub.{name}"])
-        worst = max(worst, rel(sub, want))
+        ex_n, ref_n = float(G7[f"f64.norm.{name}"]), float(G7[f"norm.{name}"])
+        e_hip_n, e_ref_n = abs(float(p.grad.norm()) - ex_n) / ex_n, abs(ref_n - ex_n) / ex_n
+        assert e_hip_n <= max(1.5 * e_ref_n, 2e-5), (name, e_hip_n, e_ref_n)
+        sub = p.grad.reshape(-1)[::gi.GRAD_STRIDE].cpu().double()
+        ex, rf = torch.from_numpy(G7[f"f64.sub.{name}"]), torch.from_numpy(G7[f"sub.{name}"]).double()
+        e_hip, e_ref = rel(sub, ex), rel(rf, ex)
+        assert e_hip <= max(1.5 * e_ref, 2e-5), (name, e_hip, e_ref)
+        worst_hip, worst_ref, worst_pair = max(worst_hip, e_hip), max(worst_ref, e_ref), max(worst_pair, rel(sub, rf))
         n += 1
-    print(f"worst relative error of the sampled gradients over {n} tensors: {worst:.2e}")
-    assert n == 21 and worst < 5e-3
+    print(f"sampled gradients over {n} tensors, worst relative error vs float64: HIP {worst_hip:.2e}, reference fp32 {worst_ref:.2e}; "
+          f"HIP vs reference {worst_pair:.2e}")
+    assert n == 21 and worst_pair < 5e-3
     params = [p for nme, p in net.named_parameters() if p.requires_grad and not nme.startswith("vq.books")]
     opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=1e-5)
     gn = torch.nn.utils.clip_grad_norm_(params, 3.0)
