@@ -20,9 +20,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "det_math.hpp"
 
 namespace mvq {
+
+struct ConvArgs;
+inline bool conv_dma_rows_ok(const ConvArgs& a);
+
+// 16 bytes of zeros in global memory: what the LDS-DMA staging reads for pieces that lie outside their row (conv zero padding)
+__device__ __attribute__((aligned(16))) static const float g_zero16[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
 // Per-launch HIP-event profiler (api.hip; mvq_profile_begin / mvq_profile_end in include/mvq.h).  Off: prof_begin returns -1
 // and nothing is recorded.  On: one event pair per kernel launch on the launch stream, with the launch's algorithmic FLOPs.
@@ -52,6 +59,7 @@ struct ConvArgs {
     int row_fast;           // 0: grid (column tiles, row tiles).  R > 0: 1-D grid, XCD-aware: the R row tiles of a column
                             // tile are consecutive on ONE XCD (workgroup id mod 8), so the x tile is fetched into that L2 once
     int act;
+    int dma;                // 1: stage the K chunks with global -> LDS DMA (3-deep ring); set by the launcher for eligible shapes
     int up_s, up_p;         // UPS: stride S and torch padding P
     int vec4;               // input rows are 16-byte aligned (Tin % 4 == 0 and x 16-byte aligned)
     int ovec4;              // output (and residual) rows are 16-byte aligned (Tout % 4 == 0, pointers aligned)
@@ -102,6 +110,12 @@ struct ConvCfg {
                                                                                                                 : (WAVES_M * WAVES_N) / 2;
     static constexpr int LDS_FLOATS_FUSE = STAGE_FLOATS > CT_FLOATS ? STAGE_FLOATS : CT_FLOATS;   // fused unit: full tile
     static constexpr int MIN_WPE_FUSE = (FOUR_WAVES && (LDS_FLOATS_FUSE + 2 * BM) * 4 <= 53 * 1024) ? 3 : (WAVES_M * WAVES_N) / 2;
+    // LDS-DMA ring: a stage is the weight chunk followed by the activation chunk with dense rows (pitch XV*4), three stages
+    static constexpr int XV4 = XV * 4;
+    static constexpr int DMA_STAGE_FLOATS = W_FLOATS + CK * XV4;
+    static constexpr int DMA_NV = DMA_STAGE_FLOATS / 4;                  // float4 pieces per stage
+    static constexpr int DMA_NU = (DMA_NV + 64 * WAVES_M * WAVES_N - 1) / (64 * WAVES_M * WAVES_N);   // DMA instructions per wave per chunk
+    static constexpr int LDS_FLOATS_DMA = 3 * DMA_STAGE_FLOATS > CTH_FLOATS ? 3 * DMA_STAGE_FLOATS : CTH_FLOATS;
     static constexpr int W_VEC = W_FLOATS / 4;                           // float4 per chunk
     static constexpr int NTHR = 64 * WAVES_M * WAVES_N;                  // threads per block
     static constexpr int W_PER_THREAD = (W_VEC + NTHR - 1) / NTHR;
@@ -319,6 +333,98 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         }
     };
 
+    if (VEC && !FUSE && a.dma) {
+        // ---- K loop with global -> LDS DMA staging (global_load_lds_dwordx4: 16 bytes per lane, 1 KiB per wave-instruction,
+        // no register round trip, no ds_write) into a ring of THREE stages: while chunk c is multiplied out of stage c % 3 the
+        // DMA of chunk c+2 is in flight into stage (c+2) % 3, which was last read during chunk c-1, i.e. before the barrier
+        // every wave passed at the end of that iteration.  What is left in a wave's instruction stream besides MFMAs and
+        // operand reads: DMA_NU DMA issues + pointer increments per chunk, one vmcnt wait and one barrier.
+        // Out-of-row pieces (the zero padding of the conv) read a 16-byte block of zeros instead.
+        constexpr int NU = C::DMA_NU;
+        constexpr int XP = C::XV4;                                        // dense activation rows
+        constexpr int D_CROSS_D = XP - (KS - 1) * DIL;
+        const int bd_same = b_base + h * D_SAME;
+        const int bd_cross = b_base + h * D_CROSS_D;
+        // per-lane source pointers of this thread's NU pieces (piece p = tid + u*NTHR of the stage), advanced per chunk
+        const float* src[NU];
+        bool live[NU];
+        long long step_b[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int p = tid + u * C::NTHR;
+            live[u] = p < C::DMA_NV;
+            if (p < C::W_VEC) {
+                const int row = p / (C::BM / 4), c4 = p - row * (C::BM / 4);
+                src[u] = a.wp + (size_t)row * a.Mpad + m0 + c4 * 4;
+                step_b[u] = (long long)CK * KS * a.Mpad;
+            } else {
+                const int q = (p < C::DMA_NV ? p : C::DMA_NV - 1) - C::W_VEC;
+                const int cl = q / C::XV, v = q - cl * C::XV;
+                const int g = g_al + 4 * v;
+                const bool ok = g >= 0 && g < a.Tin;
+                src[u] = ok ? tile.xb + (size_t)cl * a.Tin + g : g_zero16;
+                step_b[u] = ok ? (long long)CK * a.Tin : 0;
+            }
+        }
+        const unsigned lds0 = (unsigned)(size_t)smem;                    // LDS byte address of the ring
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        // DMA instructions this wave really issues per chunk (the last one is skipped by waves whose 64 pieces all lie past the end)
+        const int n_issue = (NU - 1) * C::NTHR + wave_u * 64 < C::DMA_NV ? NU : NU - 1;
+        auto dma_chunk = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                // this wave-instruction fills 1 KiB at stage base + (u*NTHR + wave*64) * 16 bytes
+                const unsigned dst = lds0 + (unsigned)(stage * C::DMA_STAGE_FLOATS * 4) + (unsigned)((u * C::NTHR + wave_u * 64) * 16);
+                if ((u + 1) * C::NTHR <= C::DMA_NV || live[u])
+                    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src[u]) : "memory");
+                src[u] += step_b[u];
+            }
+        };
+        auto mfma_chunk_dma = [&](int stage, bool issue_next, int next_stage) __attribute__((always_inline)) {
+            const float* wsrc = smem + stage * C::DMA_STAGE_FLOATS + a_base;
+            const float* xs_same = smem + stage * C::DMA_STAGE_FLOATS + C::W_FLOATS + bd_same;
+            const float* xs_cross = smem + stage * C::DMA_STAGE_FLOATS + C::W_FLOATS + bd_cross;
+            float av[2][MT], bv[2][NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[0][i] = wsrc[i * 32];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[0][j] = ((1 / KS) != 0 ? xs_cross : xs_same)[j * 32 * STRIDE];
+            if (issue_next) dma_chunk(next_stage);         // behind the first operand reads: issued while those are in flight
+#pragma unroll
+            for (int s = 0; s < C::KC / 2; ++s) {
+                if (s + 1 < C::KC / 2) {
+                    const int k0 = 2 * (s + 1);
+                    const int off0 = (k0 / KS) * XP + (k0 % KS) * DIL;
+                    const bool cross = ((k0 + 1) / KS) != (k0 / KS);
+                    const float* xsp = cross ? xs_cross : xs_same;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) av[(s + 1) & 1][i] = wsrc[2 * (s + 1) * C::BM + i * 32];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bv[(s + 1) & 1][j] = xsp[off0 + j * 32 * STRIDE];
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+            }
+        };
+        dma_chunk(0);
+        if (n_chunks > 1) dma_chunk(1);
+        int st_c = 0, st_n2 = 2;                       // stage of chunk c / of chunk c+2
+        for (int c = 0; c < n_chunks; ++c) {
+            // chunk c has landed when at most the DMA_NU instructions of chunk c+1 are still outstanding
+            if (c + 1 >= n_chunks) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (n_issue == NU) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NU) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NU - 1) : "memory");
+            __syncthreads();                          // ... in every wave; and stage (c+2)%3 is free (read during chunk c-1)
+            mfma_chunk_dma(st_c, c + 2 < n_chunks, st_n2);
+            st_c = st_c == 2 ? 0 : st_c + 1;
+            st_n2 = st_n2 == 2 ? 0 : st_n2 + 1;
+        }
+    } else {
     tile.load_chunk(0, wreg, xv, xs);
     __syncthreads();                                  // alpha table visible
     tile.store_chunk(0, 0, wreg, xv, xs);
@@ -334,6 +440,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         __syncthreads();
     }
     mfma_chunk((n_chunks - 1) & 1);
+    }
 
     // ---------------------------------------------------------------- fused ResidualUnit tail (FUSE)
     // The block owns ALL channels of its time tile (BM == C), so the 1x1 conv of the ResidualUnit runs here:
@@ -621,7 +728,9 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
               (!a.residual || (reinterpret_cast<uintptr_t>(a.residual) & 15) == 0) &&
               (!a.y2 || (reinterpret_cast<uintptr_t>(a.y2) & 15) == 0) &&
               (!a.dsn_src || (reinterpret_cast<uintptr_t>(a.dsn_src) & 15) == 0);
-    const size_t lds = (size_t)C::LDS_FLOATS * 4 + (a.alpha_in ? (size_t)2 * a.Cin * 4 : 0);
+    // LDS-DMA staging whenever the rows allow it and the 3-stage ring leaves room for at least two blocks per CU
+    a.dma = (conv_dma_rows_ok(a) && (size_t)C::LDS_FLOATS_DMA * 4 <= 64 * 1024) ? 1 : 0;
+    const size_t lds = a.dma ? (size_t)C::LDS_FLOATS_DMA * 4 : (size_t)C::LDS_FLOATS * 4 + (a.alpha_in ? (size_t)2 * a.Cin * 4 : 0);
     auto kern = conv1d_mfma_kernel<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -659,6 +768,15 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
     hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), lds, stream, a);
     prof_end(pi, stream);
     return hipGetLastError();
+}
+
+// LDS-DMA staging (conv1d_mfma_body) needs 16-byte rows and no Snake on load (the DMA cannot transform what it copies).
+// Dispatchers use this to pick the instantiation whose 3-stage ring fits three blocks per CU (smaller CK where needed).
+// MVQ_NO_DMA=1 in the environment switches it off (A/B measurements).
+inline bool conv_dma_rows_ok(const ConvArgs& a)
+{
+    static const bool off = getenv("MVQ_NO_DMA") != nullptr;
+    return !off && !a.alpha_in && a.Tin % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
 }
 
 // tile-shape selection shared by the packers and the launchers: padded M for a given number of rows

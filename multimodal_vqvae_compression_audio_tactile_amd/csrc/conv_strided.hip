@@ -5,8 +5,10 @@
 namespace mvq {
 hipError_t launch_conv_strided(const ConvArgs& a, int stride, int bm, hipStream_t s)
 {
+    // With LDS-DMA staging (3-stage ring) the stages are halved where needed so that the ring still fits three blocks per CU.
+    const bool dma = conv_dma_rows_ok(a);
     // 96-row tiles: only the input-gradient of the last DecoderBlock's ConvTranspose1d (96 <- 192 channels, stride 2)
-    if (bm == 96 && stride == 2) return launch_conv1d_mfma<4, 2, 1, 8, 3, 1, 1, 4, 0>(a, s);
+    if (bm == 96 && stride == 2) return dma ? launch_conv1d_mfma<4, 2, 1, 4, 3, 1, 1, 4, 0>(a, s) : launch_conv1d_mfma<4, 2, 1, 8, 3, 1, 1, 4, 0>(a, s);
     if (bm != 128) return hipErrorInvalidValue;
     if (conv_prefer_small_tiles(a)) {
         switch (stride) {
@@ -21,17 +23,18 @@ hipError_t launch_conv_strided(const ConvArgs& a, int stride, int bm, hipStream_
         ConvArgs m = a, t = a;
         m.n_tiles_max = a.Ncols / 128;
         t.n_base = m.n_tiles_max * 128;
-        hipError_t e = stride == 4 ? launch_conv1d_mfma<8, 4, 1, 4, 2, 2, 2, 2, 0>(m, s) : launch_conv1d_mfma<10, 5, 1, 2, 2, 2, 2, 2, 0>(m, s);
+        hipError_t e = stride == 4 ? (dma ? launch_conv1d_mfma<8, 4, 1, 2, 2, 2, 2, 2, 0>(m, s) : launch_conv1d_mfma<8, 4, 1, 4, 2, 2, 2, 2, 0>(m, s))
+                                   : launch_conv1d_mfma<10, 5, 1, 2, 2, 2, 2, 2, 0>(m, s);
         if (e != hipSuccess) return e;
-        if (stride == 4) return tail == 96 ? launch_conv1d_mfma<8, 4, 1, 4, 1, 3, 4, 1, 0>(t, s) : launch_conv1d_mfma<8, 4, 1, 4, 2, 1, 2, 2, 0>(t, s);
+        if (stride == 4) return tail == 96 ? launch_conv1d_mfma<8, 4, 1, 2, 1, 3, 4, 1, 0>(t, s) : launch_conv1d_mfma<8, 4, 1, 2, 2, 1, 2, 2, 0>(t, s);
         return tail == 96 ? launch_conv1d_mfma<10, 5, 1, 2, 1, 3, 4, 1, 0>(t, s) : launch_conv1d_mfma<10, 5, 1, 2, 2, 1, 2, 2, 0>(t, s);
     }
     switch (stride) {
-        case 2: return launch_conv1d_mfma<4, 2, 1, 8, 2, 2, 2, 2, 0>(a, s);
-        case 4: return launch_conv1d_mfma<8, 4, 1, 4, 2, 2, 2, 2, 0>(a, s);
+        case 2: return dma ? launch_conv1d_mfma<4, 2, 1, 4, 2, 2, 2, 2, 0>(a, s) : launch_conv1d_mfma<4, 2, 1, 8, 2, 2, 2, 2, 0>(a, s);
+        case 4: return dma ? launch_conv1d_mfma<8, 4, 1, 2, 2, 2, 2, 2, 0>(a, s) : launch_conv1d_mfma<8, 4, 1, 4, 2, 2, 2, 2, 0>(a, s);
         case 5: return launch_conv1d_mfma<10, 5, 1, 2, 2, 2, 2, 2, 0>(a, s);
-        case 8: return a.Ncols <= 96 ? launch_conv1d_mfma<16, 8, 1, 2, 1, 3, 4, 1, 0>(a, s)
-                                     : launch_conv1d_mfma<16, 8, 1, 2, 2, 2, 2, 2, 0>(a, s);
+        case 8: if (a.Ncols <= 96) return dma ? launch_conv1d_mfma<16, 8, 1, 1, 1, 3, 4, 1, 0>(a, s) : launch_conv1d_mfma<16, 8, 1, 2, 1, 3, 4, 1, 0>(a, s);
+                return dma ? launch_conv1d_mfma<16, 8, 1, 1, 2, 2, 2, 2, 0>(a, s) : launch_conv1d_mfma<16, 8, 1, 2, 2, 2, 2, 2, 0>(a, s);
     }
     return hipErrorInvalidValue;
 }
