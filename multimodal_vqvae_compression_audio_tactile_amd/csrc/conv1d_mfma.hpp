@@ -109,7 +109,7 @@ struct ConvCfg {
     static constexpr int MIN_WPE = (FOUR_WAVES && LDS_FLOATS * 4 <= 53 * 1024 && !(WAVES_N == 4 && NT == 2)) ? 3
                                                                                                                 : (WAVES_M * WAVES_N) / 2;
     static constexpr int LDS_FLOATS_FUSE = STAGE_FLOATS > CT_FLOATS ? STAGE_FLOATS : CT_FLOATS;   // fused unit: full tile
-    static constexpr int MIN_WPE_FUSE = (FOUR_WAVES && (LDS_FLOATS_FUSE + 2 * BM) * 4 <= 53 * 1024) ? 3 : (WAVES_M * WAVES_N) / 2;
+    static constexpr int MIN_WPE_FUSE = (FOUR_WAVES && (LDS_FLOATS_FUSE + 5 * BM) * 4 * 3 <= 160 * 1024) ? 3 : (WAVES_M * WAVES_N) / 2;
     // LDS-DMA ring: a stage is the weight chunk followed by the activation chunk with dense rows (pitch XV*4), three stages
     static constexpr int XV4 = XV * 4;
     static constexpr int DMA_STAGE_FLOATS = W_FLOATS + CK * XV4;
@@ -234,7 +234,14 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ws = smem;                          // [2][KC][BM]
     float* const Xs = smem + 2 * C::W_FLOATS;        // [2][CK][XTP]
-    float* const Al = smem + (FUSE ? C::LDS_FLOATS_FUSE : C::LDS_FLOATS);   // [2][Cin]: alpha, 1/(alpha+1e-9) (only with alpha_in)
+    // behind the staging / epilogue region: Ep = per-row 1/(alpha+1e-9) of the epilogue Snakes for this block's BM rows
+    // -- [0] alpha_out, [1] alpha2 (dual output), [2] dsn_alpha (dgrad) or alpha_mid (fused unit) -- computed once per
+    // block (the IEEE division is ~12 VALU instructions: per element it cost more than the Snake polynomial itself, and
+    // on this chip every VALU instruction is time taken from the fp32 MFMAs: DESIGN.md section 6a);
+    // then Al = [2][Cin]: alpha, 1/(alpha+1e-9) of the input Snake (only with alpha_in)
+    float* const Ep = smem + (FUSE ? C::LDS_FLOATS_FUSE : (a.dma ? C::LDS_FLOATS_DMA : C::LDS_FLOATS));
+    constexpr int EP_MID = 2;                                // the fused unit never has a dgrad epilogue: alpha_mid takes that slot
+    float* const Al = Ep + 3 * C::BM;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -267,6 +274,16 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             const float al = a.alpha_in[c];
             Al[c] = al;
             Al[Cin + c] = 1.0f / (al + 1e-9f);
+        }
+    }
+    for (int r = tid; r < C::BM; r += C::NTHR) {
+        int m = m0 + r;
+        m = m < a.Mrows ? m : a.Mrows - 1;
+        const int ch = m / (UPS ? UPS : 1);                  // ConvTranspose1d: GEMM row (co*S + phase) -> channel co
+        const float* tabs[4] = {a.alpha_out, a.y2 ? a.alpha2 : nullptr, FUSE ? a.alpha_mid : (a.dsn_src ? a.dsn_alpha : nullptr), nullptr};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            Ep[k * C::BM + r] = tabs[k] ? 1.0f / (tabs[k][ch] + 1e-9f) : 1.0f;
         }
     }
 
@@ -457,7 +474,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             for (int r = 0; r < 16; ++r) {
                 const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float bv = a.bias ? a.bias[row] : 0.0f;
-                const float al = a.alpha_mid[row], inv = 1.0f / (al + 1e-9f);
+                const float al = a.alpha_mid[row], inv = Ep[EP_MID * C::BM + row];
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     Ht[row * C::BNP + (wn * NT + j) * 32 + l31] = det_snake(acc[i][j][r] + bv, al, inv);
@@ -521,8 +538,8 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 const int mc = mok ? m : a.Mrows - 1;
                 const int co = mc / (UPS ? UPS : 1), rr = mc - co * (UPS ? UPS : 1);
                 const float bv = ep_bias ? ep_bias[co] : 0.0f;
-                float al = 1.0f, inv = 1.0f;
-                if (snake_out) { al = a.alpha_out[co]; inv = 1.0f / (al + 1e-9f); }
+                const int lr = (wm * MT + i) * 32 + row;              // row of the block tile -> Ep
+                const float al = snake_out ? a.alpha_out[co] : 1.0f, inv = Ep[lr];
                 const size_t rowoff = ((size_t)b * a.Cout + co) * a.Tout;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
@@ -532,7 +549,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     t = ok ? t : 0;
                     float v = acc[i][j][r] + bv;
                     const bool tail = a.tvalid && t >= a.tvalid;
-                    if (ok && a.y2) { const float a2 = a.alpha2[co]; a.y2[rowoff + t] = tail ? 0.0f : det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
+                    if (ok && a.y2) a.y2[rowoff + t] = tail ? 0.0f : det_snake(v, a.alpha2[co], Ep[C::BM + lr]);
                     if (snake_out) v = det_snake(v, al, inv);
                     if (ok) a.y[rowoff + t] = tail ? 0.0f : v;
                 }
@@ -578,7 +595,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     const size_t off = ((size_t)b * a.Cout + m) * a.Tout + n;
                     v.x = v.x + bv; v.y = v.y + bv; v.z = v.z + bv; v.w = v.w + bv;
                     if (a.dsn_src) {
-                        const float ad = a.dsn_alpha[m], id = 1.0f / (ad + 1e-9f);
+                        const float ad = a.dsn_alpha[m], id = Ep[2 * C::BM + tile_row(row)];
                         const f32x4 sv = *reinterpret_cast<const f32x4*>(a.dsn_src + off);
                         v.x = v.x * det_dsnake(sv.x, ad, id); v.y = v.y * det_dsnake(sv.y, ad, id);
                         v.z = v.z * det_dsnake(sv.z, ad, id); v.w = v.w * det_dsnake(sv.w, ad, id);
@@ -589,13 +606,13 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     }
                     const int nz = (a.tvalid && n + 4 > a.tvalid) ? n + 4 - a.tvalid : 0;     // trailing pad columns of this quad
                     if (a.y2) {
-                        const float a2 = a.alpha2[m], i2 = 1.0f / (a2 + 1e-9f);
+                        const float a2 = a.alpha2[m], i2 = Ep[C::BM + tile_row(row)];
                         f32x4 w = {det_snake(v.x, a2, i2), det_snake(v.y, a2, i2), det_snake(v.z, a2, i2), det_snake(v.w, a2, i2)};
                         if (nz > 0) { w.w = 0.0f; if (nz > 1) w.z = 0.0f; if (nz > 2) w.y = 0.0f; if (nz > 3) w.x = 0.0f; }
                         *reinterpret_cast<f32x4*>(a.y2 + off) = w;
                     }
                     if (snake_out) {
-                        const float al = a.alpha_out[m], inv = 1.0f / (al + 1e-9f);
+                        const float al = a.alpha_out[m], inv = Ep[tile_row(row)];
                         v.x = det_snake(v.x, al, inv); v.y = det_snake(v.y, al, inv);
                         v.z = det_snake(v.z, al, inv); v.w = det_snake(v.w, al, inv);
                     }
@@ -615,11 +632,12 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 if (m < a.Mrows && n < a.Ncols) {
                     const size_t off = ((size_t)b * a.Cout + m) * a.Tout + n;
                     float v = Ct[row * C::BNP + col] + (ep_bias ? ep_bias[m] : 0.0f);
-                    if (a.dsn_src) { const float ad = a.dsn_alpha[m]; v = v * det_dsnake(a.dsn_src[off], ad, 1.0f / (ad + 1e-9f)); }
+                    const int lr = tile_row(row);
+                    if (a.dsn_src) v = v * det_dsnake(a.dsn_src[off], a.dsn_alpha[m], Ep[2 * C::BM + lr]);
                     if (has_res) v = v + a.residual[off];
                     const bool tail = a.tvalid && n >= a.tvalid;
-                    if (a.y2) { const float a2 = a.alpha2[m]; a.y2[off] = tail ? 0.0f : det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
-                    if (snake_out) { const float al = a.alpha_out[m]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
+                    if (a.y2) a.y2[off] = tail ? 0.0f : det_snake(v, a.alpha2[m], Ep[C::BM + lr]);
+                    if (snake_out) v = det_snake(v, a.alpha_out[m], Ep[lr]);
                     if (do_tanh) v = det_tanh(v);
                     if (do_gelu) v = det_gelu(v);
                     a.y[off] = tail ? 0.0f : v;
@@ -644,8 +662,9 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 float v = Ct[(col * S + rr) * C::BNP + nl] + (ep_bias ? ep_bias[co] : 0.0f);
                 const size_t off = ((size_t)b * a.Cout + co) * a.Tout + t;
                 const bool tail = a.tvalid && t >= a.tvalid;
-                if (a.y2) { const float a2 = a.alpha2[co]; a.y2[off] = tail ? 0.0f : det_snake(v, a2, 1.0f / (a2 + 1e-9f)); }
-                if (snake_out) { const float al = a.alpha_out[co]; v = det_snake(v, al, 1.0f / (al + 1e-9f)); }
+                const int lr = tile_row(col * S);                     // any phase row of this channel: same table entry
+                if (a.y2) a.y2[off] = tail ? 0.0f : det_snake(v, a.alpha2[co], Ep[C::BM + lr]);
+                if (snake_out) v = det_snake(v, a.alpha_out[co], Ep[lr]);
                 a.y[off] = tail ? 0.0f : v;
             }
         }
@@ -688,7 +707,7 @@ inline hipError_t launch_residual_unit(const ConvArgs& a_in, hipStream_t stream)
     a.vec4 = (a.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     a.ovec4 = (a.Tout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
               ((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0);
-    const size_t lds = (size_t)C::LDS_FLOATS_FUSE * 4 + (size_t)2 * a.Cin * 4;
+    const size_t lds = (size_t)C::LDS_FLOATS_FUSE * 4 + (size_t)3 * C::BM * 4 + (size_t)2 * a.Cin * 4;
     auto kern = residual_unit_kernel<DIL, CK, MT, NT, WAVES_M, WAVES_N>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -730,7 +749,7 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
               (!a.dsn_src || (reinterpret_cast<uintptr_t>(a.dsn_src) & 15) == 0);
     // LDS-DMA staging whenever the rows allow it and the 3-stage ring leaves room for at least two blocks per CU
     a.dma = (conv_dma_rows_ok(a) && (size_t)C::LDS_FLOATS_DMA * 4 <= 64 * 1024) ? 1 : 0;
-    const size_t lds = a.dma ? (size_t)C::LDS_FLOATS_DMA * 4 : (size_t)C::LDS_FLOATS * 4 + (a.alpha_in ? (size_t)2 * a.Cin * 4 : 0);
+    const size_t lds = (a.dma ? (size_t)C::LDS_FLOATS_DMA * 4 : (size_t)C::LDS_FLOATS * 4 + (a.alpha_in ? (size_t)2 * a.Cin * 4 : 0)) + (size_t)3 * C::BM * 4;
     auto kern = conv1d_mfma_kernel<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS>;
     static bool attr_set = false;
     if (!attr_set) {
