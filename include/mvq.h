@@ -44,7 +44,8 @@ const char* mvq_last_error(void);
  * the stream it is launched on, together with the launch's ALGORITHMIC FLOPs (2 * Cin * ks * valid rows * valid columns *
  * batch: zero-padded rows and tail tiles are not counted).  mvq_profile_end() waits for the events (it synchronises) and
  * returns one entry per kernel instantiation -- the name is the one rocprofv3 prints -- with the summed duration, FLOPs and
- * launch count.  Not capturable into a hipGraph while enabled. */
+ * launch count.  Not capturable into a hipGraph while enabled; one profiling session per process at a time (global state,
+ * not thread-safe). */
 typedef struct mvq_profile_entry {
     char kernel[96];
     double seconds;

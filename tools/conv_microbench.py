@@ -18,7 +18,7 @@ def ru(prefix, C, T, n):
             layers.append((f"{prefix}.RUd{d}", "r", C, C, 7, 1, d, T, True, True, False, n))
         return
     for d in (1, 3, 9):
-        layers.append((f"{prefix}.k7d{d}", "c", C, C, 7, 1, d, T, True, False, True, n))
+        layers.append((f"{prefix}.k7d{d}", "c", C, C, 7, 1, d, T, False, False, True, n))     # wide units get a pre-snaked input
     layers.append((f"{prefix}.k1", "c", C, C, 1, 1, 1, T, False, True, False, 3 * n))
 T = 24000; C = 64
 for i, s in enumerate((2, 4, 5, 8)):
