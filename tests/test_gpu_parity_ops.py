@@ -371,3 +371,59 @@ def test_zero_padded_rows_conv_transpose(B, Cin, Tin, Cout, s, orc, dev):
     xp = np.zeros((B, Cin, Tip), np.float32); xp[..., :Tin] = x
     y = ops.conv_transpose1d(_t(xp, dev), wp, Cout, s, pad, bias=_t(b, dev), tout_rows=Tn).cpu().numpy()
     assert y.shape[-1] == Tn and np.array_equal(y, want)
+
+
+def test_profiler_entry_points(dev):
+    """mvq_profile_begin / mvq_profile_end: one entry per kernel instantiation with its launch count and algorithmic FLOPs
+    (the split launches of a T = 600 row report their own column shares), nothing recorded while off."""
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    B, C, T = 8, 512, 600
+    x = torch.randn(B, C, T, device=dev)
+    wp = ops.pack_conv1d(torch.randn(C, C, 7, device=dev) / math.sqrt(C * 7))
+    ops.conv1d(x, wp, C, 7, dil=3, pad=9)                       # not profiled
+    ops.profile_begin()
+    for _ in range(3):
+        ops.conv1d(x, wp, C, 7, dil=3, pad=9)
+    prof = ops.profile_end()
+    assert sum(v["launches"] for v in prof.values()) == 6, prof        # 3 x (four 128-column tiles + one 96-column tail launch)
+    main = prof["conv1d_mfma_kernel<7, 1, 3, 4, 2, 2, 2, 2, 0>"]; tail = prof["conv1d_mfma_kernel<7, 1, 3, 4, 1, 3, 4, 1, 0>"]
+    per_col = 2.0 * C * C * 7 * B
+    assert main["launches"] == 3 and abs(main["flops"] - 3 * per_col * 512) < 1 and abs(tail["flops"] - 3 * per_col * 88) < 1
+    assert main["seconds"] > 0 and tail["seconds"] > 0
+    assert ops.profile_end() == {}                               # a second end without begin: empty, profiler off
+    ops.conv1d(x, wp, C, 7, dil=3, pad=9)
+    ops.profile_begin(); assert ops.profile_end() == {}
+
+
+def test_dma_and_register_staging_agree(dev):
+    """The LDS-DMA staged K loop (default for 16-byte rows) and the register-staged loop (MVQ_NO_DMA=1) are the same
+    arithmetic: bit-equal outputs on a wide k7, a 1x1 with residual + dual Snake output, a strided and a transposed conv."""
+    import os, subprocess, sys
+    code = r'''
+import hashlib, math, sys, torch
+sys.path.insert(0, %r)
+from multimodal_vqvae_compression_audio_tactile_amd import ops
+g = torch.Generator().manual_seed(11)
+dev = torch.device("cuda:0")
+r = lambda *s: torch.randn(*s, generator=g).to(dev)
+outs = []
+x = r(6, 256, 600); w = r(256, 256, 7) / 42.0
+outs.append(ops.conv1d(x, ops.pack_conv1d(w), 256, 7, bias=r(256), dil=9, pad=27, alpha_out=torch.rand(256, generator=g).to(dev) + 0.5))
+w1 = r(256, 256, 1) / 16.0
+outs += list(ops.conv1d(x, ops.pack_conv1d(w1), 256, 1, bias=r(256), residual=r(6, 256, 600), alpha_dual=torch.rand(256, generator=g).to(dev) + 0.5))
+ws = r(512, 256, 10) / 50.0
+outs.append(ops.conv1d(r(4, 256, 3000), ops.pack_conv1d(ws), 512, 10, stride=5, pad=3))
+wt = r(768, 384, 10) / 40.0
+outs.append(ops.conv_transpose1d(r(6, 768, 600), ops.pack_conv_transpose1d(wt, 5), 384, 5, 3, bias=r(384)))
+torch.cuda.synchronize()
+print(hashlib.sha256(b"".join(o.cpu().numpy().tobytes() for o in outs)).hexdigest())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for no_dma in (False, True):
+        env = {k: v for k, v in os.environ.items() if k != "MVQ_NO_DMA"}
+        if no_dma:
+            env["MVQ_NO_DMA"] = "1"
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        digests.append(res.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1]
