@@ -329,7 +329,7 @@ def main():
     torch.cuda.synchronize()
 
     kev = None
-    if not args.no_kernel_events and not train:           # (the train step is reported without the per-kernel table)
+    if not args.no_kernel_events:                          # train: forward (saving form) + decoder input-gradient convs
         kev = KernelEvents(ops)
 
     barrier()
