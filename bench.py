@@ -254,7 +254,9 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
-        use_gloo = one_dev or args.backend == "gloo"
+        # MVQ_BENCH_REHEARSE_RCCL_FAILURE=1 (test hook): keep RCCL although every rank sits on cuda:0, which RCCL refuses --
+        # exercises the fatal path (the job must end non-zero within seconds, not hang)
+        use_gloo = (one_dev and os.environ.get("MVQ_BENCH_REHEARSE_RCCL_FAILURE") != "1") or args.backend == "gloo"
         if world > 1 and not one_dev and args.backend == "gloo":
             print(f"[bench rank {rank}] --backend gloo with distinct devices: collectives go over the host", file=sys.stderr)
         if use_gloo:
