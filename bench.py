@@ -229,6 +229,11 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
+    # stdout carries exactly ONE line (rank 0's JSON): whatever libraries print on fd 1 while they come up (gloo's rank
+    # banner, RCCL's version banner) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -420,7 +425,8 @@ def main():
             except Exception as ex:       # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "token-frames/s", "cores": torch.get_num_threads(),
                                         "kind": "port", "sample": f"failed: {ex!r}"}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()
