@@ -159,7 +159,6 @@ def cpu_baseline_train(books, embed, sd):
 def self_launch(args) -> int:
     """Bare ``python bench.py --gpus N`` (N > 1, no WORLD_SIZE): start the N ranks as a child job.  This process has made
     no GPU call (device_count() does not initialise HIP on this image) and never execs: it waits and returns the child's code."""
-    import socket
     import subprocess
     one_dev = os.environ.get("MVQ_BENCH_ONE_DEVICE") == "1"
     ndev = torch.cuda.device_count()
@@ -167,11 +166,10 @@ def self_launch(args) -> int:
         print(f"bench.py: --gpus {args.gpus} but only {ndev} HIP device(s) visible (set MVQ_BENCH_ONE_DEVICE=1 for the "
               "one-device rehearsal of the multi-rank path)", file=sys.stderr)
         return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    # the launcher picks the rendezvous port itself (--standalone: c10d store on a free port of its own choosing), so there is
+    # no window in which another job on the node can take a port this process probed and released
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", str(Path(__file__).resolve())] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes on this pool)
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
@@ -206,23 +204,37 @@ def pmc_traffic_table():
 
 def latency_b1(mvq, synth, dev, books, embed, sd):
     """B = 1 latency in the reference's own protocol (Evaluation/dac_vcpwq_proposed6_latency.py:489-525): 1 s of zeros,
-    3 warm-ups, 10 repeats, device synchronised before each clock read; encode_latents and T_DEC timed separately."""
+    3 warm-ups, 10 repeats, device synchronised before each clock read; encode_latents and T_DEC timed separately -- eager
+    (one host call per kernel launch) and replayed as ONE hipGraph each (graphs.GraphedCall; outputs bit-equal to eager)."""
+    from multimodal_vqvae_compression_audio_tactile_amd.graphs import GraphedCall
     net = mvq.build_proposed(sd, rvq_books=books, rvq_embed=embed, device=dev)
     a = torch.zeros(1, 1, 24000, device=dev); t = torch.zeros(1, 1, 24000, device=dev)
     for _ in range(3):
         z = net.encode_latents(a, t, books_use=books); net.T_DEC(z)
     torch.cuda.synchronize()
-    enc, dec = [], []
-    for _ in range(10):
-        t0 = time.perf_counter(); z = net.encode_latents(a, t, books_use=books); torch.cuda.synchronize()
-        enc.append((time.perf_counter() - t0) * 1e3)
-    for _ in range(10):
-        t0 = time.perf_counter(); net.T_DEC(z); torch.cuda.synchronize()
-        dec.append((time.perf_counter() - t0) * 1e3)
-    return {"encode_ms": sum(enc) / len(enc), "decode_ms": sum(dec) / len(dec), "encode_min_ms": min(enc), "decode_min_ms": min(dec),
-            "protocol": "B=1, 1 s of zeros @ 24 kHz, 3 warm-ups + 10 repeats, sync before each clock read; fp32 exact path",
-            "reference_published": {"encode_ms": [12.8, 16.3], "decode_ms": [2.75, 2.86], "hardware": "unstated CUDA GPU, AMP",
-                                    "source": "Evaluation/eval_vs_dac24_with_vcpwq_rawPSNR_latency/eval_all_vs_dac24_vcpwq_rawPSNR_latency.json:89-90"}}
+
+    def timed(fn):
+        ts = []
+        for _ in range(10):
+            t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return ts, out
+    enc, z = timed(lambda: net.encode_latents(a, t, books_use=books))
+    dec, y = timed(lambda: net.T_DEC(z))
+    res = {"encode_ms": sum(enc) / len(enc), "decode_ms": sum(dec) / len(dec), "encode_min_ms": min(enc), "decode_min_ms": min(dec),
+           "protocol": "B=1, 1 s of zeros @ 24 kHz, 3 warm-ups + 10 repeats, sync before each clock read; fp32 exact path",
+           "reference_published": {"encode_ms": [12.8, 16.3], "decode_ms": [2.75, 2.86], "hardware": "unstated CUDA GPU, AMP",
+                                   "source": "Evaluation/eval_vs_dac24_with_vcpwq_rawPSNR_latency/eval_all_vs_dac24_vcpwq_rawPSNR_latency.json:89-90"}}
+    try:
+        g_enc = GraphedCall(lambda aa, tt: net.encode_latents(aa, tt, books_use=books), a, t)
+        g_dec = GraphedCall(lambda zz: net.T_DEC(zz), z)
+        genc, zg = timed(lambda: g_enc(a, t))
+        gdec, yg = timed(lambda: g_dec(z))
+        res["graph_replay"] = {"encode_ms": sum(genc) / len(genc), "decode_ms": sum(gdec) / len(gdec), "encode_min_ms": min(genc),
+                               "decode_min_ms": min(gdec), "bit_equal_to_eager": bool(torch.equal(zg, z) and torch.equal(yg, y))}
+    except Exception as ex:
+        res["graph_replay"] = {"error": repr(ex)}
+    return res
 
 
 def main():
@@ -307,6 +319,16 @@ def main():
         params = [p for n, p in net.named_parameters() if p.requires_grad and not n.startswith("vq.books")]
         opt = (torch.optim.AdamW if args.torch_optim else mvq.optim.AdamW)(params, lr=2e-4, weight_decay=1e-5)   # ...5.py:54-55,367
 
+    phase_ev = []                # train: per step, (name, start event, end event) on the current stream = the stream of every launch
+
+    def phase(name, fn):
+        if not train or not collect_phases:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = fn(); e1.record()
+        phase_ev.append((name, e0, e1))
+        return r
+
     def step():
         if train:                                                # Training/compare_dacvsproposal_5.py:379-397
             with torch.enable_grad():
@@ -315,29 +337,39 @@ def main():
                 opt.zero_grad(set_to_none=True)
                 total.backward()
             if dist:
-                mdist.allreduce_grads(params, B, group=grp)
+                phase("grad_allreduce", lambda: mdist.allreduce_grads(params, B, group=grp))
             if args.torch_optim:
                 torch.nn.utils.clip_grad_norm_(params, 3.0)
                 opt.step()
             else:
                 _, coef = mvq.optim.clip_coef(params, 3.0)      # clip_grad_norm_(params, 3.0) fused into the update
                 opt.step(clip_coef=coef)
+            toks = out["r_tokens"]
             if dist:
-                mdist.ema_step_all_ranks(net.vq, out["r_tokens"], group=grp)
-            else:
-                net.vq.ema_step(out["r_tokens"])
+                toks = phase("ema_token_allgather", lambda: mdist.gather_tokens(toks, group=grp))
+            phase("ema_assign_and_update", lambda: net.vq.ema_step(toks))       # identical update on every rank
             return out["y_hat"].detach()
         if tact:
             return net.forward_eval_tactile_only(t, books_use=None)
         return net.forward_eval(a, t, books_use=None)
 
-    for _ in range(args.warmup):
-        y = step()
+    collect_phases = False
+    launches_per_step = 0
+    for w in range(args.warmup):
+        if w == args.warmup - 1 and not args.no_kernel_events:  # count the launches of one step: the event pool is sized from it
+            ops.profile_begin()
+            y = step()
+            launches_per_step = sum(v["launches"] for v in ops.profile_end().values())
+        else:
+            y = step()
     torch.cuda.synchronize()
 
     kev = None
     if not args.no_kernel_events:                          # train: forward (saving form) + decoder input-gradient convs
+        # every event pair of the timed region exists before it starts: no hipEventCreate inside the timed loop
+        ops.profile_reserve((launches_per_step or 256) * args.steps + 64)
         kev = KernelEvents(ops)
+    collect_phases = train
 
     barrier()
     torch.cuda.synchronize()
@@ -347,6 +379,20 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    summ = kev.summary() if kev else None
+    collect_phases = False
+
+    # the same steps once more WITHOUT the per-launch events (the two event records per launch sit between back-to-back
+    # kernels): reported next to the headline so the instrumentation's cost is a number, not an assumption
+    unprof_ms = None
+    if kev and args.steps > 0:
+        n_un = min(args.steps, 3)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_un):
+            y = step()
+        torch.cuda.synchronize()
+        unprof_ms = 1e3 * (time.perf_counter() - t1) / n_un
 
     if dist:
         tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
@@ -384,8 +430,17 @@ def main():
         else:
             gf = GFLOP_PER_SEGMENT[args.workload]
             line["path_tflops"] = seg_s * gf * 1e-3 / world            # per GPU, algorithmic
+        if unprof_ms is not None:
+            line["ms_per_step_without_kernel_events"] = unprof_ms     # rank 0, untimed extra steps after the measured region
+        if train and phase_ev:
+            acc = defaultdict(float)
+            for name, e0, e1 in phase_ev:
+                acc[name] += e0.elapsed_time(e1)
+            line["train_phases_ms_per_step"] = {k: v / args.steps for k, v in acc.items()}
+            line["train_phases_ms_per_step"]["note"] = ("HIP events on the launch stream, rank 0; ema_assign_and_update = codebook "
+                                                        f"search of all {args.books} books + counting-sort update over "
+                                                        f"{B * world * TOKENS_PER_SEGMENT} gathered tokens")
         if kev:
-            summ = kev.summary()
             dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
             name, d = dom
             ach = d["flops"] / d["seconds"] * 1e-12

@@ -53,7 +53,12 @@ typedef struct mvq_profile_entry {
     int launches;
 } mvq_profile_entry;
 int mvq_profile_begin(void);
+/* writes at most max_entries rows; *n_entries = the number of rows WRITTEN (instantiations beyond the buffer are dropped).
+ * Returns MVQ_EHIP when an event could not be created or recorded during the session (first such error; nothing is written). */
 int mvq_profile_end(mvq_profile_entry* out, int max_entries, int* n_entries);
+/* creates the event pairs of n_launches launches ahead of time: call it before a timed region so that no hipEventCreate
+ * falls inside it (events are pooled and reused across sessions). */
+int mvq_profile_reserve(int n_launches);
 /* fills cu_count / lds_bytes / gcn arch name ("gfx950...") of the current device; synchronous. */
 int mvq_device_query(int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len);
 
@@ -143,8 +148,11 @@ int mvq_rvq_ema_forward_f32(const float* z, const float* books, float* q_out, in
 
 /* ResidualVQEMA.ema_step (Training/compare_dacvsproposal_5.py:266-277): every book matched against the
  * SAME tokens X = z_tokens[B,D,T]; used codes move to decay*e + (1-decay)*mean(assigned tokens).
- * books[nb,K,D] updated in place.  scratch: mvq_rvq_ema_step_scratch_bytes() bytes (the per-book
- * assignments, nb*B*T int32).  Sums are accumulated in token order (deterministic, = index_add_ order). */
+ * books[nb,K,D] updated in place.  scratch: mvq_rvq_ema_step_scratch_bytes() bytes, 16-byte aligned (the per-book
+ * assignments nb*B*T int32, then the workspace of a stable counting sort of the token ids by code + the token-major copy
+ * of X).  Per (code, dim) the sum runs over the code's OWN tokens in token order -- the additions index_add_ performs, in
+ * its order, so the result is deterministic and bit-equal to the sequential loop -- at O(B*T*D) work per book instead of
+ * O(K*D*B*T).  B*T < 2^24 (counts stay exact in fp32), K <= 16384. */
 size_t mvq_rvq_ema_step_scratch_bytes(int batch, int t, int nb, int k, int dim);
 int mvq_rvq_ema_step_f32(const float* z_tokens, float* books, void* scratch,
                          int batch, int dim, int t, int nb, int k, float decay, void* stream);

@@ -4,7 +4,8 @@ Drop-in surface:
   * ``DAC`` / ``Encoder`` / ``ResidualVectorQuantize`` / ``Decoder``  -- the dac.DAC(24 kHz) objects the reference
     pulls apart (``.encoder``, ``.quantizer``, ``.decoder``, ``.encode``, ``.decode``);
   * ``ResidualVQEMA`` / ``CrossPredictor`` / ``TokenNorm`` / ``PosEnc1D`` / ``AllPredAR`` / ``AllPredAR3`` (the compare_dacvsproposal_3.py
-    variant) / ``ProposedEval`` -- the reference's own modules, same constructors and state-dict keys;
+    variant) / ``ProposedEval`` / ``ProposedWrapper`` (compare_dacvsproposal_3.5_eval.py)
+    -- the reference's own modules, same constructors and state-dict keys;
   * ``safe_l1`` / ``MultiResSTFTLoss`` / ``MelCosineLoss`` / ``TrainingLoss`` -- the training losses (losses.py) and
     ``train`` -- the HIP-backed autograd Functions behind ``AllPredAR.forward_step(...); total.backward()``;
   * ``Resample`` / ``resample_to`` -- torchaudio.transforms.Resample as the reference calls it; ``stsim_batch``;
@@ -18,7 +19,7 @@ from .resample import Resample, resample_to  # noqa: F401
 from .losses import MelCosineLoss, MultiResSTFTLoss, TrainingLoss, safe_l1, stsim_batch  # noqa: F401
 from ._lib import MvqError, build, lib  # noqa: F401
 from .dac import DAC, Decoder, Encoder, ResidualVectorQuantize, VectorQuantize, Snake1d, WNConv1d, WNConvTranspose1d  # noqa: F401
-from .proposed import (AllPredAR, AllPredAR3, CrossPredictor, PosEnc1D, ProposedEval, ResidualVQEMA, TokenNorm,  # noqa: F401
+from .proposed import (AllPredAR, AllPredAR3, CrossPredictor, PosEnc1D, ProposedEval, ProposedWrapper, ResidualVQEMA, TokenNorm,  # noqa: F401
                        psnr_batch, psnr_global_peak_db, align_by_xcorr, crop_match, align_pair_24k,
                        psnr_3k_aligned_batch)
 

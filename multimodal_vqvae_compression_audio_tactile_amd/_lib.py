@@ -11,7 +11,10 @@ from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-SO_PATH = _PKG / "libmvq_hip.so"
+import os as _os
+# MVQ_LIB_PATH: measurement aid only (A/B runs of an alternative build of the SAME sources, tools/conv_microbench.py);
+# it names another libmvq_hip build, never a fallback implementation.
+SO_PATH = Path(_os.environ["MVQ_LIB_PATH"]).resolve() if _os.environ.get("MVQ_LIB_PATH") else _PKG / "libmvq_hip.so"
 _lib = None
 
 class ProfileEntry(ctypes.Structure):
@@ -23,6 +26,7 @@ EXPORTS = {
     # name: (restype, argtypes)
     "mvq_profile_begin": (c_int, []),
     "mvq_profile_end": (c_int, [ctypes.POINTER(ProfileEntry), c_int, ctypes.POINTER(c_int)]),
+    "mvq_profile_reserve": (c_int, [c_int]),
     "mvq_abi_version": (c_int, []),
     "mvq_last_error": (c_char_p, []),
     "mvq_device_query": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_char_p, c_int]),

@@ -19,11 +19,13 @@ struct ProfRec { std::string name; double flops; hipEvent_t e0, e1; };
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_prof_pool;          // events are reused between sessions
 bool g_prof_on = false;
+hipError_t g_prof_err = hipSuccess;           // first hipEventCreate / hipEventRecord failure of the session (reported by _end)
 hipEvent_t prof_event()
 {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    const hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) { if (g_prof_err == hipSuccess) g_prof_err = rc; return nullptr; }
     return e;
 }
 }  // namespace
@@ -31,15 +33,24 @@ bool prof_enabled() { return g_prof_on; }
 int prof_begin(const char* kernel_name, double flops, hipStream_t s)
 {
     if (!g_prof_on) return -1;
-    ProfRec r{kernel_name, flops, prof_event(), prof_event()};
-    if (!r.e0 || !r.e1) return -1;
-    (void)hipEventRecord(r.e0, s);
+    ProfRec r{kernel_name, flops, prof_event(), nullptr};
+    if (!r.e0) return -1;
+    r.e1 = prof_event();
+    if (!r.e1) { g_prof_pool.push_back(r.e0); return -1; }      // do not leak the first event when the second cannot be made
+    const hipError_t rc = hipEventRecord(r.e0, s);
+    if (rc != hipSuccess) {
+        if (g_prof_err == hipSuccess) g_prof_err = rc;
+        g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1);
+        return -1;
+    }
     g_prof.push_back(r);
     return (int)g_prof.size() - 1;
 }
 void prof_end(int idx, hipStream_t s)
 {
-    if (idx >= 0 && idx < (int)g_prof.size()) (void)hipEventRecord(g_prof[idx].e1, s);
+    if (idx < 0 || idx >= (int)g_prof.size()) return;
+    const hipError_t rc = hipEventRecord(g_prof[idx].e1, s);
+    if (rc != hipSuccess && g_prof_err == hipSuccess) g_prof_err = rc;
 }
 }  // namespace mvq
 
@@ -69,21 +80,50 @@ int mvq_profile_begin(void)
 {
     for (auto& r : mvq::g_prof) { mvq::g_prof_pool.push_back(r.e0); mvq::g_prof_pool.push_back(r.e1); }
     mvq::g_prof.clear();
+    mvq::g_prof_err = hipSuccess;
     mvq::g_prof_on = true;
+    return MVQ_OK;
+}
+
+int mvq_profile_reserve(int n_launches)
+{
+    /* create the event pairs of `n_launches` launches ahead of time, so that no hipEventCreate falls into a timed region */
+    if (n_launches < 0) return fail(MVQ_EINVAL, "profile_reserve: negative count");
+    std::vector<hipEvent_t> made;
+    const size_t want = 2 * (size_t)n_launches;
+    while (mvq::g_prof_pool.size() + made.size() < want) {
+        hipEvent_t e = nullptr;
+        const hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) { for (auto m : made) mvq::g_prof_pool.push_back(m); return hipfail(rc, "profile_reserve: hipEventCreate"); }
+        made.push_back(e);
+    }
+    for (auto m : made) mvq::g_prof_pool.push_back(m);
     return MVQ_OK;
 }
 
 int mvq_profile_end(mvq_profile_entry* out, int max_entries, int* n_entries)
 {
+    /* *n_entries = rows WRITTEN (<= max_entries); kernels beyond max_entries are dropped, never written past the buffer */
     mvq::g_prof_on = false;
-    if (!n_entries || (max_entries > 0 && !out)) return fail(MVQ_EINVAL, "profile_end: null argument");
+    if (!n_entries || max_entries < 0 || (max_entries > 0 && !out)) return fail(MVQ_EINVAL, "profile_end: bad argument");
+    *n_entries = 0;
+    auto recycle = [] {
+        for (auto& r : mvq::g_prof) { mvq::g_prof_pool.push_back(r.e0); mvq::g_prof_pool.push_back(r.e1); }
+        mvq::g_prof.clear();
+    };
+    if (mvq::g_prof_err != hipSuccess) {
+        const hipError_t e = mvq::g_prof_err;
+        mvq::g_prof_err = hipSuccess;
+        recycle();
+        return hipfail(e, "profile: an event could not be created or recorded during the session");
+    }
     std::map<std::string, mvq_profile_entry> agg;
     for (auto& r : mvq::g_prof) {
         hipError_t e = hipEventSynchronize(r.e1);
-        if (e != hipSuccess) return hipfail(e, "profile_end: hipEventSynchronize");
+        if (e != hipSuccess) { recycle(); return hipfail(e, "profile_end: hipEventSynchronize"); }
         float ms = 0.0f;
         e = hipEventElapsedTime(&ms, r.e0, r.e1);
-        if (e != hipSuccess) return hipfail(e, "profile_end: hipEventElapsedTime");
+        if (e != hipSuccess) { recycle(); return hipfail(e, "profile_end: hipEventElapsedTime"); }
         auto it = agg.find(r.name);
         if (it == agg.end()) {
             mvq_profile_entry z{};
@@ -94,14 +134,13 @@ int mvq_profile_end(mvq_profile_entry* out, int max_entries, int* n_entries)
         it->second.flops += r.flops;
         it->second.launches += 1;
     }
-    for (auto& r : mvq::g_prof) { mvq::g_prof_pool.push_back(r.e0); mvq::g_prof_pool.push_back(r.e1); }
-    mvq::g_prof.clear();
-    *n_entries = (int)agg.size();
+    recycle();
     int i = 0;
     for (auto& kv : agg) {
         if (i >= max_entries) break;
         out[i++] = kv.second;
     }
+    *n_entries = i;
     return MVQ_OK;
 }
 
@@ -391,20 +430,26 @@ int mvq_rvq_ema_forward_f32(const float* z, const float* books, float* q_out, in
 
 size_t mvq_rvq_ema_step_scratch_bytes(int batch, int t, int nb, int k, int dim)
 {
-    (void)k; (void)dim;
-    return (size_t)nb * batch * t * sizeof(int32_t);
+    if (batch <= 0 || t <= 0 || nb <= 0 || k <= 0 || dim <= 0) return 0;
+    const size_t n = (size_t)batch * t;
+    /* the per-book assignments, then the counting-sort workspace of the update (16-byte aligned) */
+    return (((size_t)nb * n * sizeof(int32_t) + 15) & ~(size_t)15) + mvq::ema_update_scratch_bytes((int)n, nb, k, dim);
 }
 
 int mvq_rvq_ema_step_f32(const float* z_tokens, float* books, void* scratch,
                          int batch, int dim, int t, int nb, int k, float decay, void* stream)
 {
     if (batch < 0 || t < 0 || dim <= 0 || dim > 128 || dim % 4 != 0 || nb <= 0 || k <= 0) return fail(MVQ_EINVAL, "rvq_ema_step: bad shape");
+    if ((long long)batch * t >= (1ll << 24)) return fail(MVQ_EUNSUPPORTED, "rvq_ema_step: at most 2^24 - 1 tokens per call (counts are kept exact in fp32)");
+    if (k > 16384) return fail(MVQ_EUNSUPPORTED, "rvq_ema_step: K <= 16384 (the per-segment histogram lives in LDS)");
     if (batch * t == 0) return MVQ_OK;
     if (!z_tokens || !books || !scratch) return fail(MVQ_EINVAL, "rvq_ema_step: null tensor");
     int32_t* idx = reinterpret_cast<int32_t*>(scratch);
+    const size_t n = (size_t)batch * t;
+    void* work = reinterpret_cast<char*>(scratch) + (((size_t)nb * n * sizeof(int32_t) + 15) & ~(size_t)15);
     hipError_t e = mvq::launch_rvq_ema_forward(z_tokens, books, nullptr, idx, batch, dim, t, nb, k, 0, S(stream));
     if (e != hipSuccess) return hipfail(e, "rvq_ema_step(assign)");
-    e = mvq::launch_ema_update(z_tokens, idx, books, batch, dim, t, nb, k, decay, S(stream));
+    e = mvq::launch_ema_update(z_tokens, idx, books, work, batch, dim, t, nb, k, decay, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "rvq_ema_step(update)");
 }
 

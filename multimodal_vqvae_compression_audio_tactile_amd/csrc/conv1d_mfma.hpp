@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "det_math.hpp"
+#include "kernels_small.hpp"
 
 namespace mvq {
 
@@ -392,8 +393,14 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             for (int u = 0; u < NU; ++u) {
                 // this wave-instruction fills 1 KiB at stage base + (u*NTHR + wave*64) * 16 bytes
                 const unsigned dst = lds0 + (unsigned)(stage * C::DMA_STAGE_FLOATS * 4) + (unsigned)((u * C::NTHR + wave_u * 64) * 16);
-                if ((u + 1) * C::NTHR <= C::DMA_NV || live[u])
-                    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src[u]) : "memory");
+                // M0 (the LDS destination base) is compiler-reserved: it is saved, written and read inside ONE statement and
+                // restored before the statement ends; s_nop 0 = the wait state gfx9 needs between an SALU write of M0 and the
+                // LDS-DMA instruction that reads it (the assembler pads nothing inside an asm string).
+                if ((u + 1) * C::NTHR <= C::DMA_NV || live[u]) {
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src[u]), "s"(dst) : "memory");
+                }
                 src[u] += step_b[u];
             }
         };
@@ -709,12 +716,10 @@ inline hipError_t launch_residual_unit(const ConvArgs& a_in, hipStream_t stream)
               ((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0);
     const size_t lds = (size_t)C::LDS_FLOATS_FUSE * 4 + (size_t)3 * C::BM * 4 + (size_t)2 * a.Cin * 4;
     auto kern = residual_unit_kernel<DIL, CK, MT, NT, WAVES_M, WAVES_N>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {
+        static BigLdsOptIn opt;                       // per (kernel instantiation, device)
+        const hipError_t e = opt.ensure(reinterpret_cast<const void*>(kern));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     dim3 grid((unsigned)(a.n_tiles * a.B), 1);
     int pi = -1;
@@ -751,12 +756,10 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
     a.dma = (conv_dma_rows_ok(a) && (size_t)C::LDS_FLOATS_DMA * 4 <= 64 * 1024) ? 1 : 0;
     const size_t lds = (a.dma ? (size_t)C::LDS_FLOATS_DMA * 4 : (size_t)C::LDS_FLOATS * 4 + (a.alpha_in ? (size_t)2 * a.Cin * 4 : 0)) + (size_t)3 * C::BM * 4;
     auto kern = conv1d_mfma_kernel<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {
+        static BigLdsOptIn opt;                       // per (kernel instantiation, device)
+        const hipError_t e = opt.ensure(reinterpret_cast<const void*>(kern));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned gx = (unsigned)(a.n_tiles * a.B), R = (unsigned)((a.Mrows + C::BM - 1) / C::BM);

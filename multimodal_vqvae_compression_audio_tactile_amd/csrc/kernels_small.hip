@@ -493,16 +493,10 @@ hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamm
     if (n == 0) return hipSuccess;
     const size_t lds = ((size_t)C * 32 + 2 * 32) * sizeof(float);
     if (lds <= 160 * 1024) {
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_c_tile_kernel<32>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_c_tile_kernel<4>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr = true;
-        }
+        static BigLdsOptIn opt32, opt4;
+        hipError_t e = opt32.ensure(reinterpret_cast<const void*>(layernorm_c_tile_kernel<32>));
+        if (e == hipSuccess) e = opt4.ensure(reinterpret_cast<const void*>(layernorm_c_tile_kernel<4>));
+        if (e != hipSuccess) return e;
         if (n <= 64)
             hipLaunchKernelGGL(layernorm_c_tile_kernel<4>, dim3((n + 3) / 4), dim3(256), ((size_t)C * 4 + 8) * sizeof(float), s,
                                x, pe, gamma, beta, y, B, C, T, sb, sc, eps, do_tanh, post_scale, sub);

@@ -6,6 +6,24 @@
 
 namespace mvq {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): one flag per device ordinal, so a process that
+// drives several GPUs opts every one of them in (a single per-process flag would leave the second device at the 64 KB default).
+constexpr int kMaxLdsOptInDevices = 64;
+struct BigLdsOptIn {
+    bool done[kMaxLdsOptInDevices] = {};
+    hipError_t ensure(const void* kern)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const bool tracked = dev >= 0 && dev < kMaxLdsOptInDevices;
+        if (tracked && done[dev]) return hipSuccess;
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess && tracked) done[dev] = true;
+        return e;
+    }
+};
+
 int prof_begin(const char* kernel_name, double flops, hipStream_t s);     // api.hip (see conv1d_mfma.hpp)
 void prof_end(int idx, hipStream_t s);
 bool prof_enabled();
@@ -70,7 +88,8 @@ hipError_t launch_align_xcorr(const float* r, const float* e, int T, int max_shi
 
 hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_out, int32_t* idx_out,
                                   int B, int D, int T, int nb, int K, int update_residual, hipStream_t s);
-hipError_t launch_ema_update(const float* z, const int32_t* idx, float* books, int B, int D, int T, int nb, int K,
+size_t ema_update_scratch_bytes(int N, int nb, int K, int D);
+hipError_t launch_ema_update(const float* z, const int32_t* idx, float* books, void* scratch, int B, int D, int T, int nb, int K,
                              float decay, hipStream_t s);
 hipError_t launch_dac_rvq(const float* z, const float* in_w, const float* in_b, const float* cb, const float* out_w,
                           const float* out_b, float* zq, int32_t* codes, float* latents, const int32_t* nq_item,

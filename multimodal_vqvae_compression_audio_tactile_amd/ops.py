@@ -103,6 +103,11 @@ def profile_begin() -> None:
     check(_lib.lib().mvq_profile_begin(), "mvq_profile_begin")
 
 
+def profile_reserve(n_launches: int) -> None:
+    """Pre-create the event pairs of `n_launches` kernel launches (keeps hipEventCreate out of a timed region)."""
+    check(_lib.lib().mvq_profile_reserve(int(n_launches)), "mvq_profile_reserve")
+
+
 def profile_end() -> dict:
     """Stop and collect: {kernel instantiation name: {"seconds", "flops", "launches"}} (synchronises)."""
     import ctypes

@@ -1,5 +1,5 @@
 """The reference's own modules on the hot path, same names / constructor arguments / state-dict keys, running on
-libmvq_hip.so:  PosEnc1D, TokenNorm, CrossPredictor, ResidualVQEMA, AllPredAR (forward), ProposedEval.
+libmvq_hip.so:  PosEnc1D, TokenNorm, CrossPredictor, ResidualVQEMA, AllPredAR (forward), ProposedEval, ProposedWrapper.
 
 Reference: Training/compare_dacvsproposal_5.py:214-326 (train-time classes) and
 Evaluation/dac_vcpwq_proposed6_latency.py:339-487 (eval-time classes with ``n_books_use`` / ``encode_latents``).
@@ -352,6 +352,28 @@ class ProposedEval(_ProposedBase):
     @torch.no_grad()
     def forward_eval_tactile_only(self, t_1T, books_use=None):
         return self.T_DEC(self.encode_latents_tactile_only(t_1T, books_use))
+
+
+RVQ_N_BOOKS_MAX = 10  # Evaluation/compare_dacvsproposal_3.5_eval.py:68
+RVQ_EMBED = 128       # ...:69
+
+
+class ProposedWrapper(_ProposedBase):
+    """The eval wrapper of Evaluation/compare_dacvsproposal_3.5_eval.py:374-411: constructor
+    ``(A_ENC, A_QUANT, T_ENC, T_DEC, c_lat)`` -- the RVQ shape comes from that script's module constants
+    ``RVQ_N_BOOKS_MAX = 10`` x ``RVQ_EMBED = 128`` (...:68-69; built at ...:485) -- and ``forward_eval(a, t, books_use)`` with a
+    REQUIRED ``books_use`` (swept over 1..3 at ...:504).  Its AR loop writes ``zt_prev[...] = z_run[..., s-1:e-1]`` for
+    s > 0 and ``zt_prev[..., 1:] = z_run[..., s:e-1]`` for s == 0 (...:393-396): the entries of z_run read for positions
+    1.. have not been written yet, so -- exactly as in the other scripts -- only column 0 of a chunk with s > 0 is non-zero
+    and the launch plan is ``_ar_latents`` unchanged."""
+
+    def __init__(self, A_ENC, A_QUANT, T_ENC, T_DEC, c_lat):
+        super().__init__(A_ENC, A_QUANT, T_ENC, T_DEC, c_lat, RVQ_N_BOOKS_MAX, RVQ_EMBED)
+
+    @torch.no_grad()
+    def forward_eval(self, a_1T, t_1T, books_use: int):
+        qa, zt = self._encode_branches(a_1T, t_1T)
+        return self.T_DEC(self._ar_latents(qa, zt, int(books_use))[0])
 
 
 class AllPredAR(_ProposedBase):

@@ -64,3 +64,7 @@ def evaluation():
 
 def eval5():
     return load("Evaluation/compare_dacvsproposal_5_eval.py", "ref_eval5")
+
+
+def eval35():
+    return load("Evaluation/compare_dacvsproposal_3.5_eval.py", "ref_eval35")

@@ -27,6 +27,10 @@ patched) and records inputs-by-seed + expected outputs of:
   G8 stsim_batch (Evaluation/compare_dacvsproposal_5_eval.py:142-177), MelScale stand-in as in G7
   G9 psnr_3k_aligned_batch (Evaluation/compare_dacvsproposal_5_eval.py:188-223): align at 24 kHz, resample to 3 kHz, PSNR;
      torchaudio's Resample replaced by the restated resampler (oracle), as MelScale is in G7/G8
+  G11 compare_dacvsproposal_3.5_eval.py: its ``ProposedWrapper`` (Evaluation/...3.5_eval.py:374-411; constructor
+     ``(A_ENC, A_QUANT, T_ENC, T_DEC, c_lat)``, RVQ 10 x 128 from the script's constants) swept over ``books_use`` 1..3 as its
+     ``eval_proposed`` does (...:504): per sweep point y, the z_run handed to T_DEC, per-book idx + margins, psnr_batch.
+     (``python tests/golden/make_golden.py g11`` regenerates this fixture alone.)
   G5 psnr_batch / psnr_global_peak_db (Evaluation/compare_dacvsproposal_5_eval.py:180-185, ...6_latency.py:204-214)
 Only data is stored (arrays), never reference source.  Inputs are re-created from seeds by tests/golden_inputs.py.
 """
@@ -93,8 +97,38 @@ def audio_codes_with_margins(dac_model, a):
     return codes.numpy().astype(np.int16), mar.numpy().astype(np.float32), sca.numpy().astype(np.float32)
 
 
+def make_g11():
+    """G11: the ProposedWrapper of compare_dacvsproposal_3.5_eval.py on the restated backbones, books_use in {1, 2, 3}."""
+    e35, e5 = ref_import.eval35(), ref_import.eval5()
+    seed, B, uses = gi.PW_CASE
+    assert (e35.RVQ_N_BOOKS_MAX, e35.RVQ_EMBED, e35.CODE_DIM) == (10, 128, 96) and e35.DAC_NQ_LIST == [1, 4, 8, 16, 32]
+    sdm = gi.model_state(seed, e35.RVQ_N_BOOKS_MAX, e35.RVQ_EMBED)
+    a, t = gi.pw_inputs()
+    da, dt = T.DAC(), T.DAC()
+    net = e35.ProposedWrapper(da.encoder, da.quantizer, dt.encoder, dt.decoder, c_lat=1024)      # ...3.5_eval.py:485
+    missing, unexpected = net.load_state_dict(sdm, strict=False)                                 # ...:487 (strict=False)
+    assert not missing and not unexpected
+    net.eval()
+    g = {}
+    g["codes"], g["codes_margin"], g["codes_scale"] = audio_codes_with_margins(da, a)
+    seen = {}
+    hook = net.T_DEC.register_forward_hook(lambda mod, inp, out: seen.__setitem__("z_run", inp[0].detach().clone()))
+    for use in uses:
+        with RecordNearest(e35.ResidualVQEMA) as rec:
+            y = net.forward_eval(a, t, books_use=int(use))
+        g[f"use{use}.idx"], g[f"use{use}.margin"], g[f"use{use}.scale"] = rec.stacked(use, B)
+        g[f"use{use}.z_run"] = seen["z_run"].numpy()
+        g[f"use{use}.y"] = y.numpy()
+        g[f"use{use}.psnr"] = np.array(e5.psnr_batch(t[..., :y.shape[-1]], y), np.float64)
+    hook.remove()
+    np.savez_compressed(OUT / "g11_proposed_wrapper.npz", **g)
+
+
 def main():
     assert ref_import.available(), "reference not mounted"
+    if sys.argv[1:] == ["g11"]:
+        make_g11()
+        return
     tr, ev, e5 = ref_import.training(), ref_import.evaluation(), ref_import.eval5()
 
     # ---- G1: RVQ forward
@@ -258,6 +292,7 @@ def main():
                         scale=sca, codes=codes, codes_margin=cmar, codes_scale=csca,
                         losses=np.array([float(l1), float(st), float(me), float(total)], np.float64),
                         psnr=np.array(e5.psnr_batch(tg, yh), np.float64))
+    make_g11()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size // 1024, "KiB")
 

@@ -23,6 +23,8 @@ T_SHORT = 320 * 35
 TRAIN_CASE = (3, 128, 2, 23, 320 * 24)
 # G10 compare_dacvsproposal_3.py (BASELINE.json configs[0]): (RVQ_N_BOOKS, RVQ_EMBED, CODE_DIM, seed); ONE full 1-s pair
 CFG3 = (10, 128, 96, 31)
+# G11 compare_dacvsproposal_3.5_eval.py ProposedWrapper: (seed, B, books_use swept); RVQ shape = that script's constants
+PW_CASE = (41, 2, (1, 2, 3))
 GRAD_STRIDE = 997            # stored subsample of every gradient tensor: flat[::GRAD_STRIDE]
 
 
@@ -53,6 +55,12 @@ def model_state(seed, books, K):
 
 def pe_inputs(B, seed):
     from multimodal_vqvae_compression_audio_tactile_amd import synth
+    return synth.audio_segments(B, seed=seed, T=T_SHORT), synth.tactile_segments(B, seed=seed, T=T_SHORT)
+
+
+def pw_inputs():
+    from multimodal_vqvae_compression_audio_tactile_amd import synth
+    seed, B, _ = PW_CASE
     return synth.audio_segments(B, seed=seed, T=T_SHORT), synth.tactile_segments(B, seed=seed, T=T_SHORT)
 
 

@@ -107,8 +107,11 @@ def test_bench_gpu_count_contract():
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MVQ_BENCH_ONE_DEVICE")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+    # hide every GPU from the child: on a multi-GPU host the first call would otherwise start a real 2-rank benchmark
+    env.update(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
     assert r.returncode == 2 and "HIP device" in r.stderr and not r.stdout.strip()
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0"),
-                       capture_output=True, text=True)
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr and not r.stdout.strip()
