@@ -262,43 +262,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     under_launcher = "WORLD_SIZE" in os.environ
-    dist, grp, backend_used, rccl_ranks = None, None, None, None
+    dist, grp, backend_used, rccl_ranks, ranks = None, None, None, None, None
     if under_launcher:
-        # The rendezvous goes over gloo (host only: cannot fail for GPU reasons and gives every rank a way to learn that a
-        # peer died).  The data-path group is RCCL and has to PROVE itself: one all-reduce of ones must return the world
-        # size on every rank.  Failure is fatal (the rank exits non-zero, the launcher stops the job).
-        import datetime
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
-        # MVQ_BENCH_REHEARSE_RCCL_FAILURE=1 (test hook): keep RCCL although every rank sits on cuda:0, which RCCL refuses --
-        # exercises the fatal path (the job must end non-zero within seconds, not hang)
-        use_gloo = (one_dev and os.environ.get("MVQ_BENCH_REHEARSE_RCCL_FAILURE") != "1") or args.backend == "gloo"
-        if world > 1 and not one_dev and args.backend == "gloo":
-            print(f"[bench rank {rank}] --backend gloo with distinct devices: collectives go over the host", file=sys.stderr)
-        if use_gloo:
-            backend_used = "gloo (one-device rehearsal)" if one_dev else "gloo"
-        else:
-            try:
-                grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
-                probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe, group=grp)
-                torch.cuda.synchronize()
-                rccl_ranks = int(round(float(probe.item())))
-            except Exception as ex:
-                fatal(rank, f"RCCL group did not come up ({type(ex).__name__}: {ex})")
-            if rccl_ranks != world:
-                fatal(rank, f"RCCL all-reduce of ones returned {rccl_ranks}, expected {world}")
-            backend_used = "nccl"
-    red_dev = dev if backend_used == "nccl" else torch.device("cpu")
+        # gloo rendezvous, then an RCCL group that has to complete one all-reduce of ones on every rank (dist.bring_up); failure
+        # is fatal.  MVQ_BENCH_REHEARSE_RCCL_FAILURE=1 (test hook): keep RCCL although every rank sits on cuda:0, which RCCL
+        # refuses -- exercises the fatal path (the job must end non-zero within seconds, not hang)
+        from multimodal_vqvae_compression_audio_tactile_amd import dist as mdist_
+        ranks = mdist_.bring_up(rank, world, local_rank, backend=args.backend, one_device=one_dev,
+                                rehearse_failure=os.environ.get("MVQ_BENCH_REHEARSE_RCCL_FAILURE") == "1")
+        dist, grp, backend_used, rccl_ranks = ranks.dist, ranks.group, ranks.backend, ranks.rccl_ranks
+    red_dev = ranks.reduce_device if ranks else torch.device("cpu")
 
     def barrier():
-        if dist is None:
-            return
-        if backend_used == "nccl":
-            dist.barrier(group=grp, device_ids=[local_rank])
-        else:
-            dist.barrier()
+        if ranks:
+            ranks.barrier()
 
     import multimodal_vqvae_compression_audio_tactile_amd as mvq
     from multimodal_vqvae_compression_audio_tactile_amd import ops, synth

@@ -220,6 +220,11 @@ int mvq_copy3d_f32(const float* a, size_t a_sb, size_t a_sc, float* y, size_t y_
  * (device).  One launch pair instead of 2*max_shift+1 reductions with a host comparison each. */
 int mvq_align_xcorr_f32(const float* ref, const float* est, int t, int max_shift, float* corr, int32_t* scratch,
                         int32_t* best_shift, void* stream);
+/* The same for `batch` pairs in ONE launch pair (rows of pitch t; corr / scratch [batch][2*max_shift+1], best_shift[batch]):
+ * psnr_3k_aligned_batch (Evaluation/compare_dacvsproposal_5_eval.py:212-223) aligns every item of a batch.  Per item the
+ * chains are those of mvq_align_xcorr_f32, so the shifts are identical. */
+int mvq_align_xcorr_batch_f32(const float* ref, const float* est, int batch, int t, int max_shift, float* corr, int32_t* scratch,
+                              int32_t* best_shift, void* stream);
 
 /* ---- backward w.r.t. the decoder input (weights are frozen in the reference) ----- */
 
@@ -327,6 +332,12 @@ int mvq_conv_transpose1d_padded_f32(const float* x, const float* wp, const float
  * len_out <= ceil(newf*len/orig).  One fp32 fma chain per output sample, k ascending (bit-exact vs the oracle). */
 int mvq_resample_f32(const float* x, const float* kern, float* y, int batch, int len, int len_out, int orig, int newf,
                      int width, int ks, void* stream);
+/* Ragged form (the resample step of psnr_3k_aligned_batch, ...5_eval.py:217-220, after a per-item alignment shift): item b
+ * resamples x[b*pitch + off[b] : ... + len[b]]; off / len are DEVICE int32 arrays (they are computed from the device-side
+ * shifts, so no host round trip sits between aligning and resampling).  y rows have pitch lout_pitch; samples at and past
+ * ceil(newf*len[b]/orig) are written as zeros and that length goes to len_out[b] (may be NULL).  Same chains as above. */
+int mvq_resample_ragged_f32(const float* x, const float* kern, float* y, const int32_t* off, const int32_t* len, int32_t* len_out,
+                            int batch, int pitch, int lout_pitch, int orig, int newf, int width, int ks, void* stream);
 
 /* Optimiser step of the training config (torch.optim.AdamW + clip_grad_norm_, Training/compare_dacvsproposal_5.py:367,394-395):
  *   sumsq_partial : partial[n_partial] block sums of x^2 (their total is the squared gradient norm), n_partial <= 4096

@@ -52,6 +52,8 @@ EXPORTS = {
     "mvq_layernorm_c_f32": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_size_t] * 2 + [c_float, c_int, c_float, c_void_p]),
     "mvq_attention_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_size_t] * 4 + [c_void_p]),
     "mvq_align_xcorr_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mvq_align_xcorr_batch_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mvq_resample_ragged_f32": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "mvq_conv1d_dgrad_packed_floats": (c_size_t, [c_int] * 3),
     "mvq_conv1d_pack_dgrad_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mvq_conv_transpose1d_pack_dgrad_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -345,7 +345,10 @@ int mvq_residual_unit_padded_f32(const float* x, const float* x_snaked, const fl
     if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "residual_unit: y2 and alpha2 go together");
     if (ru_fusable(c, dil)) {
         mvq::ConvArgs a{};
-        a.x = x; a.wp = w7p; a.bias = b7; a.alpha_in = alpha_a; a.residual = x; a.alpha_out = alpha_next; a.y = y;
+        /* x_snaked = snake_a(x) from the producer's dual output: the unit stages it as is (LDS-DMA ring, no Snake on load);
+         * the skip path still adds the RAW x in the epilogue */
+        a.x = x_snaked ? x_snaked : x; a.wp = w7p; a.bias = b7; a.alpha_in = x_snaked ? nullptr : alpha_a; a.residual = x;
+        a.alpha_out = alpha_next; a.y = y;
         a.B = batch; a.Cin = c; a.Tin = t; a.Cout = c; a.Tout = t; a.pad = 3 * dil; a.Mpad = mvq::conv_mpad(c);
         a.Mrows = c; a.Ncols = t; a.act = 0; a.up_s = 1; a.up_p = 0;
         a.alpha_mid = alpha_b; a.w2p = w1p; a.bias2 = b1; a.y2 = y2; a.alpha2 = alpha2;
@@ -541,6 +544,28 @@ int mvq_align_xcorr_f32(const float* ref, const float* est, int t, int max_shift
     if (!ref || !est || !corr || !scratch || !best_shift) return fail(MVQ_EINVAL, "align_xcorr: null tensor");
     hipError_t e = mvq::launch_align_xcorr(ref, est, t, max_shift, corr, scratch, best_shift, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "align_xcorr");
+}
+
+int mvq_align_xcorr_batch_f32(const float* ref, const float* est, int batch, int t, int max_shift, float* corr, int32_t* scratch,
+                              int32_t* best_shift, void* stream)
+{
+    if (batch < 0 || t < 0 || max_shift < 0) return fail(MVQ_EINVAL, "align_xcorr_batch: bad shape");
+    if (batch == 0) return MVQ_OK;
+    if (!ref || !est || !corr || !scratch || !best_shift) return fail(MVQ_EINVAL, "align_xcorr_batch: null tensor");
+    hipError_t e = mvq::launch_align_xcorr_batch(ref, est, batch, t, max_shift, corr, scratch, best_shift, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "align_xcorr_batch");
+}
+
+int mvq_resample_ragged_f32(const float* x, const float* kern, float* y, const int32_t* off, const int32_t* len, int32_t* len_out,
+                            int batch, int pitch, int lout_pitch, int orig, int newf, int width, int ks, void* stream)
+{
+    if (batch < 0 || pitch < 0 || lout_pitch < 0 || orig <= 0 || newf <= 0 || width < 0 || ks != 2 * width + orig)
+        return fail(MVQ_EINVAL, "resample_ragged: bad shape (ks must be 2*width + orig)");
+    if ((long long)lout_pitch < ((long long)newf * 0 + orig - 1) / orig) return fail(MVQ_EINVAL, "resample_ragged: bad output pitch");
+    if (batch == 0 || lout_pitch == 0) return MVQ_OK;
+    if (!x || !kern || !y || !off || !len) return fail(MVQ_EINVAL, "resample_ragged: null tensor");
+    hipError_t e = mvq::launch_resample_ragged(x, kern, y, off, len, len_out, batch, pitch, lout_pitch, orig, newf, width, ks, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "resample_ragged");
 }
 
 /* ---- backward (input-gradient) entry points: SURVEY.md section 8f row f1 ------------------------------------- */

@@ -84,6 +84,23 @@ struct ConvArgs {
     int name_len;
 };
 
+// k-steps per operand-read group (see conv1d_mfma_body).  Double-buffered groups (the reads of group g+1 are in flight
+// during the MFMAs of group g) get 2 x 16 operand registers, single-buffered ones 28; a divisor of the chunk's k-step count is
+// preferred (no ragged last group).  A/B builds: -DMVQ_KGROUP=n fixes the group size (1 = one k-step per group, the round-2
+// schedule), -DMVQ_KPREFETCH=0 selects the single-buffered form.
+#ifndef MVQ_KPREFETCH
+#define MVQ_KPREFETCH 1
+#endif
+constexpr int kgroup_steps(int ns, int regs_per_step)
+{
+#ifdef MVQ_KGROUP
+    return MVQ_KGROUP < ns ? MVQ_KGROUP : ns;
+#else
+    (void)ns; (void)regs_per_step;
+    return 1;
+#endif
+}
+
 template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, int UPS>
 struct ConvCfg {
     static constexpr int BM = 32 * MT * WAVES_M;
@@ -117,6 +134,8 @@ struct ConvCfg {
     static constexpr int DMA_NV = DMA_STAGE_FLOATS / 4;                  // float4 pieces per stage
     static constexpr int DMA_NU = (DMA_NV + 64 * WAVES_M * WAVES_N - 1) / (64 * WAVES_M * WAVES_N);   // DMA instructions per wave per chunk
     static constexpr int LDS_FLOATS_DMA = 3 * DMA_STAGE_FLOATS > CTH_FLOATS ? 3 * DMA_STAGE_FLOATS : CTH_FLOATS;
+    // fused unit fed by LDS-DMA (its input arrives pre-snaked): the 3-stage ring, then the full intermediate / epilogue tile
+    static constexpr int LDS_FLOATS_FUSE_DMA = 3 * DMA_STAGE_FLOATS > CT_FLOATS ? 3 * DMA_STAGE_FLOATS : CT_FLOATS;
     static constexpr int W_VEC = W_FLOATS / 4;                           // float4 per chunk
     static constexpr int NTHR = 64 * WAVES_M * WAVES_N;                  // threads per block
     static constexpr int W_PER_THREAD = (W_VEC + NTHR - 1) / NTHR;
@@ -240,7 +259,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     // block (the IEEE division is ~12 VALU instructions: per element it cost more than the Snake polynomial itself, and
     // on this chip every VALU instruction is time taken from the fp32 MFMAs: DESIGN.md section 6a);
     // then Al = [2][Cin]: alpha, 1/(alpha+1e-9) of the input Snake (only with alpha_in)
-    float* const Ep = smem + (FUSE ? C::LDS_FLOATS_FUSE : (a.dma ? C::LDS_FLOATS_DMA : C::LDS_FLOATS));
+    float* const Ep = smem + (FUSE ? (a.dma ? C::LDS_FLOATS_FUSE_DMA : C::LDS_FLOATS_FUSE) : (a.dma ? C::LDS_FLOATS_DMA : C::LDS_FLOATS));
     constexpr int EP_MID = 2;                                // the fused unit never has a dgrad epilogue: alpha_mid takes that slot
     float* const Al = Ep + 3 * C::BM;
 
@@ -319,39 +338,57 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     // one chunk of MFMAs out of LDS buffer `buf`; operands of k-step s+1 are fetched before the MFMAs of step s
     // (Skipping the MFMAs of column subtiles that lie past the end of the row was measured: +0.3 % -- the block lasts as long
     // as its busiest wave.  Rows with a mostly empty last tile are split into two launches instead: conv_tail_width.)
+    // Operand reads are issued in GROUPS of KG k-steps, one group ahead of the MFMAs that consume them: a wave's stream is
+    // [reads of group g+1][MFMAs of group g] with one lgkmcnt wait per group instead of one per k-step.  Measured on the box
+    // (tools/mfma_probe.hip, profiles/r03_mfma_probe.jsonl): an LDS-fed 32x32x2 loop whose reads come in batches of 4
+    // k-steps runs at 151-153 TFLOP/s with 2-3 waves per SIMD; with a read / wait / MFMA hand-over at every k-step, 136.
+    constexpr int NS = C::KC / 2;                                       // k-steps per chunk
+    constexpr int KG = kgroup_steps(NS, MT + NT);
+    constexpr int NG = (NS + KG - 1) / KG;
+    constexpr bool KPRE = MVQ_KPREFETCH != 0;
     auto mfma_chunk = [&](int buf) __attribute__((always_inline)) {
         const float* wsrc = Ws + buf * C::W_FLOATS + a_base;
         const float* xs_same = Xs + buf * C::X_FLOATS + b_same;
         const float* xs_cross = Xs + buf * C::X_FLOATS + b_cross;
-        float av[2][MT], bv[2][NT];
+        float av[KPRE ? 2 : 1][KG][MT], bv[KPRE ? 2 : 1][KG][NT];
+        auto load_group = [&](int g, int pb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) av[0][i] = wsrc[i * 32];
+            for (int u = 0; u < KG; ++u) {
+                const int st = g * KG + u;
+                if (st < NS) {
+                    const int k0 = 2 * st;
+                    const int off0 = (k0 / KS) * C::XTP + (k0 % KS) * DIL;
+                    const bool cross = ((k0 + 1) / KS) != (k0 / KS);
+                    const float* xsp = cross ? xs_cross : xs_same;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bv[0][j] = ((1 / KS) != 0 ? xs_cross : xs_same)[j * 32 * STRIDE];
+                    for (int i = 0; i < MT; ++i) av[pb][u][i] = wsrc[k0 * C::BM + i * 32];
 #pragma unroll
-        for (int s = 0; s < C::KC / 2; ++s) {
-            if (s + 1 < C::KC / 2) {
-                const int k0 = 2 * (s + 1);
-                const int off0 = (k0 / KS) * C::XTP + (k0 % KS) * DIL;
-                const bool cross = ((k0 + 1) / KS) != (k0 / KS);
-                const float* xsp = cross ? xs_cross : xs_same;
-#pragma unroll
-                for (int i = 0; i < MT; ++i) av[(s + 1) & 1][i] = wsrc[2 * (s + 1) * C::BM + i * 32];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bv[(s + 1) & 1][j] = xsp[off0 + j * 32 * STRIDE];
+                    for (int j = 0; j < NT; ++j) bv[pb][u][j] = xsp[off0 + j * 32 * STRIDE];
+                }
             }
+        };
+        if (KPRE) load_group(0, 0);
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+        for (int g = 0; g < NG; ++g) {
+            const int pb = KPRE ? (g & 1) : 0;
+            if (KPRE) { if (g + 1 < NG) load_group(g + 1, (g + 1) & 1); }
+            else load_group(g, 0);
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
-            // operand reads of step s+1 first, then the MFMAs of step s (keeps a full k-step of latency cover)
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+            for (int u = 0; u < KG; ++u)
+                if (g * KG + u < NS) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[pb][u][i], bv[pb][u][j], acc[i][j], 0, 0, 0);
+                }
+            // the reads (of group g+1 when prefetching, of this group otherwise) first, then the MFMAs of group g
+            __builtin_amdgcn_sched_group_barrier(0x100, (MT + NT) * KG, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT * KG, 0);
         }
     };
 
-    if (VEC && !FUSE && a.dma) {
+    if (VEC && a.dma) {
         // ---- K loop with global -> LDS DMA staging (global_load_lds_dwordx4: 16 bytes per lane, 1 KiB per wave-instruction,
         // no register round trip, no ds_write) into a ring of THREE stages: while chunk c is multiplied out of stage c % 3 the
         // DMA of chunk c+2 is in flight into stage (c+2) % 3, which was last read during chunk c-1, i.e. before the barrier
@@ -408,36 +445,59 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             const float* wsrc = smem + stage * C::DMA_STAGE_FLOATS + a_base;
             const float* xs_same = smem + stage * C::DMA_STAGE_FLOATS + C::W_FLOATS + bd_same;
             const float* xs_cross = smem + stage * C::DMA_STAGE_FLOATS + C::W_FLOATS + bd_cross;
-            float av[2][MT], bv[2][NT];
+            float av[KPRE ? 2 : 1][KG][MT], bv[KPRE ? 2 : 1][KG][NT];
+            auto load_group = [&](int g, int pb) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[0][i] = wsrc[i * 32];
+                for (int u = 0; u < KG; ++u) {
+                    const int st = g * KG + u;
+                    if (st < NS) {
+                        const int k0 = 2 * st;
+                        const int off0 = (k0 / KS) * XP + (k0 % KS) * DIL;
+                        const bool cross = ((k0 + 1) / KS) != (k0 / KS);
+                        const float* xsp = cross ? xs_cross : xs_same;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bv[0][j] = ((1 / KS) != 0 ? xs_cross : xs_same)[j * 32 * STRIDE];
+                        for (int i = 0; i < MT; ++i) av[pb][u][i] = wsrc[k0 * C::BM + i * 32];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) bv[pb][u][j] = xsp[off0 + j * 32 * STRIDE];
+                    }
+                }
+            };
+            load_group(0, 0);
             if (issue_next) dma_chunk(next_stage);         // behind the first operand reads: issued while those are in flight
 #pragma unroll
-            for (int s = 0; s < C::KC / 2; ++s) {
-                if (s + 1 < C::KC / 2) {
-                    const int k0 = 2 * (s + 1);
-                    const int off0 = (k0 / KS) * XP + (k0 % KS) * DIL;
-                    const bool cross = ((k0 + 1) / KS) != (k0 / KS);
-                    const float* xsp = cross ? xs_cross : xs_same;
+            for (int g = 0; g < NG; ++g) {
+                const int pb = KPRE ? (g & 1) : 0;
+                if (KPRE) { if (g + 1 < NG) load_group(g + 1, (g + 1) & 1); }
+                else if (g > 0) load_group(g, 0);
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) av[(s + 1) & 1][i] = wsrc[2 * (s + 1) * C::BM + i * 32];
+                for (int u = 0; u < KG; ++u)
+                    if (g * KG + u < NS) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) bv[(s + 1) & 1][j] = xsp[off0 + j * 32 * STRIDE];
-                }
+                        for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+                            for (int j = 0; j < NT; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[pb][u][i], bv[pb][u][j], acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_group_barrier(0x100, (MT + NT) * KG, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT * KG, 0);
             }
         };
         dma_chunk(0);
         if (n_chunks > 1) dma_chunk(1);
         int st_c = 0, st_n2 = 2;                       // stage of chunk c / of chunk c+2
+#ifdef MVQ_EXP      // TIMING EXPERIMENTS ONLY (wrong results): bit 0 = no DMA in the steady state, bit 1 = no wait / barrier per chunk
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int c = 0; c < n_chunks; ++c) {
+            if (!(MVQ_EXP & 2)) {
+                if (c + 1 >= n_chunks) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (n_issue == NU) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NU) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NU - 1) : "memory");
+                __syncthreads();
+            }
+            mfma_chunk_dma(c & 1, (MVQ_EXP & 1) ? false : (c + 2 < n_chunks), 2);
+        }
+#else
         for (int c = 0; c < n_chunks; ++c) {
             // chunk c has landed when at most the DMA_NU instructions of chunk c+1 are still outstanding
             if (c + 1 >= n_chunks) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -448,6 +508,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             st_c = st_c == 2 ? 0 : st_c + 1;
             st_n2 = st_n2 == 2 ? 0 : st_n2 + 1;
         }
+#endif
     } else {
     tile.load_chunk(0, wreg, xv, xs);
     __syncthreads();                                  // alpha table visible
@@ -529,6 +590,19 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     // tanh and the global stores run row-contiguous: 16-byte residual loads and stores when rows are aligned,
     // 4-byte but fully coalesced otherwise.  (ConvTranspose phases whose count does not divide BM keep the
     // direct per-lane store.)
+#if defined(MVQ_EXP) && (MVQ_EXP & 4)
+    {   // TIMING EXPERIMENT: no epilogue (one store keeps the accumulators alive)
+        float sink = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sink += acc[i][j][r];
+        if (sink == 123.456f) a.y[0] = sink;
+        return;
+    }
+#endif
     const bool has_res = (UPS == 0) && a.residual != nullptr;
     const bool snake_out = a.alpha_out != nullptr;
     const bool do_tanh = a.act == 1;
@@ -714,7 +788,10 @@ inline hipError_t launch_residual_unit(const ConvArgs& a_in, hipStream_t stream)
     a.vec4 = (a.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     a.ovec4 = (a.Tout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
               ((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0);
-    const size_t lds = (size_t)C::LDS_FLOATS_FUSE * 4 + (size_t)3 * C::BM * 4 + (size_t)2 * a.Cin * 4;
+    // input already carries its Snake (the producer's dual output) and rows are 16-byte: the 7-tap stage runs on the LDS-DMA ring
+    a.dma = (conv_dma_rows_ok(a) && ((size_t)C::LDS_FLOATS_FUSE_DMA + 3 * C::BM) * 4 * 2 <= 160 * 1024) ? 1 : 0;
+    const size_t lds = a.dma ? (size_t)C::LDS_FLOATS_FUSE_DMA * 4 + (size_t)3 * C::BM * 4
+                             : (size_t)C::LDS_FLOATS_FUSE * 4 + (size_t)3 * C::BM * 4 + (size_t)2 * a.Cin * 4;
     auto kern = residual_unit_kernel<DIL, CK, MT, NT, WAVES_M, WAVES_N>;
     {
         static BigLdsOptIn opt;                       // per (kernel instantiation, device)

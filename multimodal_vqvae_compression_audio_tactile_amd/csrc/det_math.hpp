@@ -95,55 +95,58 @@ __device__ __forceinline__ float det_gelu(float x)
     return (0.5f * x) * (1.0f + det_erf(x * 0.707106781186547524f));
 }
 
-// sin(y)^2 with period-pi reduction and ONE even polynomial (no quadrant select): ~17 VALU ops instead of ~35 for
-// sin() then squaring -- Snake is the dominant VALU cost of the conv staging loops and epilogues.
-__device__ __forceinline__ float det_sin2(float y)
+// Snake needs sin(alpha*x)^2.  Working in TURNS removes the range reduction's Cody-Waite chain: t = x * (alpha/pi) is the phase
+// in half-periods, n = rint(t), f = t - n is EXACT in fp32 (|f| <= 0.5, both operands multiples of ulp(t)), and
+// sin(pi f)^2 = v*(c1 + c2 v + ... + c9 v^8), v = f^2 (Taylor in pi*f, truncation < 2e-9 at |f| = 0.5; measured 1.7e-7 abs
+// against libm over |t| <= 8).  14 VALU operations per Snake instead of 18 (round 2: mul, mul, rint, 3 fma of Cody-Waite, mul,
+// 8 fma, mul, fma) -- on this chip every VALU instruction is time the fp32 MFMAs do not get (tools/mfma_probe.hip).
+// The phase rounds twice (alpha/pi, then the product with x) where torch's sin(alpha*x) rounds once: the same order of error
+// (~1e-7 * |alpha x|) as the reference's own fp32 product, far inside every tolerance the fixtures are compared with.
+__device__ __forceinline__ float det_sin2_turns(float t)
 {
-    const float n = __builtin_rintf(y * 0.318309886183790672f);
-    float r = dfma(-n, 3.140625f, y);
-    r = dfma(-n, 9.67502593994140625e-4f, r);
-    r = dfma(-n, 1.509957990978376e-7f, r);
-    const float u = r * r;
-    float p = dfma(u, 2.04724070e-11f, -1.56613913e-09f);
-    p = dfma(u, p, 9.39683479e-08f);
-    p = dfma(u, p, -4.27555983e-06f);
-    p = dfma(u, p, 1.41093474e-04f);
-    p = dfma(u, p, -3.17460317e-03f);
-    p = dfma(u, p, 4.44444444e-02f);
-    p = dfma(u, p, -3.33333333e-01f);
-    p = dfma(u, p, 1.0f);
-    return u * p;
+    const float n = __builtin_rintf(t);
+    const float f = t - n;
+    const float v = f * f;
+    float p = dfma(v, 0.018191421404480934f, -0.14100298285484314f);
+    p = dfma(v, p, 0.8571953773498535f);
+    p = dfma(v, p, -3.951768159866333f);
+    p = dfma(v, p, 13.213128089904785f);
+    p = dfma(v, p, -30.1223201751709f);
+    p = dfma(v, p, 42.72840881347656f);
+    p = dfma(v, p, -32.469696044921875f);
+    p = dfma(v, p, 9.869604110717773f);
+    return v * p;
 }
 
-// inv_alpha = 1.0f / (alpha + 1e-9f), precomputed once per channel (same IEEE division everywhere)
+// inv_alpha = 1.0f / (alpha + 1e-9f), precomputed once per channel (same IEEE division everywhere); alpha * (1/pi) is one
+// fp32 product per call site (hoisted out of the per-element loops by the compiler: alpha is per row)
 __device__ __forceinline__ float det_snake(float x, float alpha, float inv_alpha)
 {
-    return dfma(inv_alpha, det_sin2(alpha * x), x);
+    return dfma(inv_alpha, det_sin2_turns(x * (alpha * 0.318309886183790672f)), x);
 }
 
-// sin(y) with the period-pi reduction of det_sin2: one odd polynomial, sign from the parity of n
-__device__ __forceinline__ float det_sin_pi(float y)
+// sin(pi*t): n = rint(t), f = t - n exact, one odd polynomial f*(d0 + d1 v + ... + d7 v^7), sign from the parity of n
+__device__ __forceinline__ float det_sin_turns(float t)
 {
-    const float n = __builtin_rintf(y * 0.318309886183790672f);
-    float r = dfma(-n, 3.140625f, y);
-    r = dfma(-n, 9.67502593994140625e-4f, r);
-    r = dfma(-n, 1.509957990978376e-7f, r);
-    const float u = r * r;
-    float p = dfma(u, -7.64716373e-13f, 1.60590438e-10f);
-    p = dfma(u, p, -2.50521084e-08f);
-    p = dfma(u, p, 2.75573192e-06f);
-    p = dfma(u, p, -1.98412698e-04f);
-    p = dfma(u, p, 8.33333333e-03f);
-    p = dfma(u, p, -1.66666667e-01f);
-    const float s = dfma(r * u, p, r);
+    const float n = __builtin_rintf(t);
+    const float f = t - n;
+    const float v = f * f;
+    float p = dfma(v, -2.191535349993501e-05f, 0.0004663027939386666f);
+    p = dfma(v, p, -0.00737043097615242f);
+    p = dfma(v, p, 0.08214588463306427f);
+    p = dfma(v, p, -0.5992645025253296f);
+    p = dfma(v, p, 2.550163984298706f);
+    p = dfma(v, p, -5.167712688446045f);
+    p = dfma(v, p, 3.1415927410125732f);
+    const float s = f * p;
     return ((int)n & 1) ? -s : s;
 }
 
-// d snake(x)/dx = 1 + (alpha/(alpha+1e-9)) * sin(2*alpha*x)   (backward of Snake1d)
+// d snake(x)/dx = 1 + (alpha/(alpha+1e-9)) * sin(2*alpha*x)   (backward of Snake1d); 2*alpha*x = pi * (2t)
 __device__ __forceinline__ float det_dsnake(float x, float alpha, float inv_alpha)
 {
-    const float ax = alpha * x;
-    return dfma(alpha * inv_alpha, det_sin_pi(ax + ax), 1.0f);
+    const float t = x * (alpha * 0.318309886183790672f);
+    return dfma(alpha * inv_alpha, det_sin_turns(t + t), 1.0f);
 }
 
 }  // namespace mvq

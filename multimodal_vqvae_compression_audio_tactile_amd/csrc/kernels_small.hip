@@ -661,6 +661,55 @@ __global__ void xcorr_pick_kernel(const float* __restrict__ corr, const int* __r
     *best_shift = best_s;
 }
 
+// batched form: grid.y = item (rows of pitch T); the per-shift chain is the same, so every item's result equals the
+// single-item launch bit for bit
+__global__ void xcorr_batch_kernel(const float* __restrict__ r, const float* __restrict__ e, int T, int max_shift,
+                                   float* __restrict__ corr, int* __restrict__ valid)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > 2 * max_shift) return;
+    const int b = blockIdx.y, n1 = 2 * max_shift + 1;
+    const float* rb = r + (size_t)b * T;
+    const float* eb = e + (size_t)b * T;
+    const int s = k - max_shift;
+    const int n = T - (s < 0 ? -s : s);
+    const float* rp = s < 0 ? rb - s : rb;
+    const float* ep = s > 0 ? eb + s : eb;
+    float c = 0.0f;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        float a[8], q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[u] = rp[i + u]; q[u] = ep[i + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c = dfma(a[u], q[u], c);
+    }
+    for (; i < n; ++i) c = dfma(rp[i], ep[i], c);
+    corr[(size_t)b * n1 + k] = n > 0 ? c : 0.0f;
+    valid[(size_t)b * n1 + k] = n > 0;
+}
+
+__global__ void xcorr_pick_batch_kernel(const float* __restrict__ corr, const int* __restrict__ valid, int max_shift,
+                                        int* __restrict__ best_shift, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n1 = 2 * max_shift + 1;
+    int best_s = 0; float best = -1e18f;
+    for (int k = 0; k < n1; ++k)
+        if (valid[(size_t)b * n1 + k] && corr[(size_t)b * n1 + k] > best) { best = corr[(size_t)b * n1 + k]; best_s = k - max_shift; }
+    best_shift[b] = best_s;
+}
+
+hipError_t launch_align_xcorr_batch(const float* r, const float* e, int B, int T, int max_shift, float* corr, int* scratch_valid,
+                                    int* best_shift, hipStream_t s)
+{
+    const int n = 2 * max_shift + 1;
+    hipLaunchKernelGGL(xcorr_batch_kernel, dim3((n + 63) / 64, B), dim3(64), 0, s, r, e, T, max_shift, corr, scratch_valid);
+    hipLaunchKernelGGL(xcorr_pick_batch_kernel, dim3((B + 63) / 64), dim3(64), 0, s, corr, scratch_valid, max_shift, best_shift, B);
+    return hipGetLastError();
+}
+
 hipError_t launch_align_xcorr(const float* r, const float* e, int T, int max_shift, float* corr, int* scratch_valid,
                               int* best_shift, hipStream_t s)
 {
@@ -697,6 +746,51 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     float acc = 0.0f;
     for (int k = k_lo; k < k_hi; ++k) acc = dfma(kp[k], xb[j0 + k], acc);
     y[(size_t)b * Lout + m] = acc;
+}
+
+// ragged form for the aligned-PSNR metric (Evaluation/compare_dacvsproposal_5_eval.py:212-223): item b resamples the slice
+// x[b][off[b] : off[b] + len[b]] (off / len on the DEVICE: they come from the alignment shifts, no host round trip);
+// y rows have pitch lout_pitch, entries past ceil(newf * len[b] / orig) are written as zeros; lout[b] receives that length.
+__global__ __launch_bounds__(256) void resample_ragged_kernel(const float* __restrict__ x, const float* __restrict__ kern,
+                                                              float* __restrict__ y, const int* __restrict__ off,
+                                                              const int* __restrict__ len, int* __restrict__ lout,
+                                                              int pitch, int lout_pitch, int orig, int newf, int width, int ks,
+                                                              int kern_in_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) float ksm[];
+    if (kern_in_lds) {
+        for (int e = threadIdx.x; e < newf * ks; e += 256) ksm[e] = kern[e];
+        __syncthreads();
+    }
+    const float* kt = kern_in_lds ? ksm : kern;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    const int L = len[b];
+    const int Lo = (int)(((long long)newf * L + orig - 1) / orig);
+    if (m == 0 && lout) lout[b] = Lo;
+    if (m >= lout_pitch) return;
+    float acc = 0.0f;
+    if (m < Lo) {
+        const int n = m / newf, p = m - n * newf;
+        const float* xb = x + (size_t)b * pitch + off[b];
+        const float* kp = kt + (size_t)p * ks;
+        const int j0 = n * orig - width;
+        int k_lo = j0 < 0 ? -j0 : 0;
+        int k_hi = ks; if (j0 + k_hi > L) k_hi = L - j0;
+        for (int k = k_lo; k < k_hi; ++k) acc = dfma(kp[k], xb[j0 + k], acc);
+    }
+    y[(size_t)b * lout_pitch + m] = acc;
+}
+
+hipError_t launch_resample_ragged(const float* x, const float* kern, float* y, const int* off, const int* len, int* lout, int B,
+                                  int pitch, int lout_pitch, int orig, int newf, int width, int ks, hipStream_t s)
+{
+    if (B == 0 || lout_pitch == 0) return hipSuccess;
+    const size_t kbytes = (size_t)newf * ks * sizeof(float);
+    const int in_lds = kbytes <= 48 * 1024;
+    hipLaunchKernelGGL(resample_ragged_kernel, dim3((lout_pitch + 255) / 256, B), dim3(256), in_lds ? kbytes : 0, s,
+                       x, kern, y, off, len, lout, pitch, lout_pitch, orig, newf, width, ks, in_lds);
+    return hipGetLastError();
 }
 
 hipError_t launch_resample(const float* x, const float* kern, float* y, int B, int L, int Lout, int orig, int newf,

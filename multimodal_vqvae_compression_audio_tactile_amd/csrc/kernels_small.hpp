@@ -83,6 +83,10 @@ hipError_t launch_resample(const float* x, const float* kern, float* y, int B, i
 hipError_t launch_sumsq_partial(const float* x, float* partial, int n_partial, size_t n, hipStream_t s);
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, const float* clip_coef, size_t n, float lr, float beta1,
                         float beta2, float eps, float weight_decay, float bc1, float sqrt_bc2, hipStream_t s);
+hipError_t launch_align_xcorr_batch(const float* r, const float* e, int B, int T, int max_shift, float* corr, int* scratch_valid,
+                                    int* best_shift, hipStream_t s);
+hipError_t launch_resample_ragged(const float* x, const float* kern, float* y, const int* off, const int* len, int* lout, int B,
+                                  int pitch, int lout_pitch, int orig, int newf, int width, int ks, hipStream_t s);
 hipError_t launch_align_xcorr(const float* r, const float* e, int T, int max_shift, float* corr, int* scratch_valid,
                               int* best_shift, hipStream_t s);
 

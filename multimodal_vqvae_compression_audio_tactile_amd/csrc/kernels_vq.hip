@@ -11,6 +11,7 @@
 //      and residual update, all stages for a block's 16 tokens with the residual held in registers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "det_math.hpp"
 #include "kernels_small.hpp"
 
@@ -386,11 +387,77 @@ static hipError_t launch_rvq_t(const float* z, const float* books, float* q_out,
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Latency form (a handful of tokens: one AR chunk of one segment is 16): ONE BLOCK PER TOKEN, thread = code.  Nothing is
+// staged: every thread walks its code rows straight out of L2 (the books are read by every block, 196 KB each at K = 512)
+// while the token's residual sits in LDS, so a 16-token chunk occupies 16 CUs instead of 2 and a book costs a row walk
+// instead of two 98 KB LDS stagings per block.  Same chains as the other forms: score = (sum_d r_d * e_d, d ascending)
+// - 0.5 * (sum_d e_d^2, d ascending); strict '>' over ascending codes, lowest index on ties.
+// LDS: res[D] | qs[D] | ws[4] | wi[4]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rvq_ema_forward_token_kernel(
+    const float* __restrict__ z, const float* __restrict__ books, float* __restrict__ q_out,
+    int32_t* __restrict__ idx_out, int B, int D, int T, int nb, int K, int update_residual)
+{
+    __shared__ float res[128], qs[128], ws[4];
+    __shared__ int wi[4];
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x, N = B * T;
+    const int b = n / T, t = n - b * T;
+    if (tid < D) { res[tid] = z[((size_t)b * D + tid) * T + t]; qs[tid] = 0.0f; }
+    for (int bk = 0; bk < nb; ++bk) {
+        const float* emb = books + (size_t)bk * K * D;
+        __syncthreads();
+        float bs = -__builtin_inff(); int bi = 0x7fffffff;
+        for (int k = tid; k < K; k += 256) {
+            const float* row = emb + (size_t)k * D;
+            float dot = 0.0f, hs = 0.0f;
+            for (int d = 0; d < D; d += 16) {                      // D % 4 == 0; up to four 16-byte row loads in flight
+                v4 e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e[u] = (d + 4 * u < D) ? *reinterpret_cast<const v4*>(row + d + 4 * u) : v4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (d + 4 * u < D) {
+                        const float* r = res + d + 4 * u;
+                        dot = dfma(r[0], e[u].x, dot); dot = dfma(r[1], e[u].y, dot); dot = dfma(r[2], e[u].z, dot); dot = dfma(r[3], e[u].w, dot);
+                        hs = dfma(e[u].x, e[u].x, hs); hs = dfma(e[u].y, e[u].y, hs); hs = dfma(e[u].z, e[u].z, hs); hs = dfma(e[u].w, e[u].w, hs);
+                    }
+            }
+            const float sc = dot - 0.5f * hs;
+            if (sc > bs) { bs = sc; bi = k; }
+        }
+        wave_argmax(bs, bi);
+        if (lane == 0) { ws[wave] = bs; wi[wave] = bi; }
+        __syncthreads();
+        float cs = ws[0]; int id = wi[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) amax_combine(cs, id, ws[w], wi[w]);
+        if (id < 0 || id >= K) id = 0;                           // all-NaN scores: defined, in-range gather
+        if (tid < D) {
+            const float q = emb[(size_t)id * D + tid];
+            const float r = res[tid];
+            qs[tid] = (qs[tid] + (q - r)) + r;
+            if (update_residual) res[tid] = r - q;
+        }
+        if (idx_out && tid == 0) idx_out[(size_t)bk * N + n] = id;
+    }
+    __syncthreads();
+    if (q_out && tid < D) q_out[((size_t)b * D + tid) * T + t] = qs[tid];
+}
+
 hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_out, int32_t* idx_out,
                                   int B, int D, int T, int nb, int K, int update_residual, hipStream_t s)
 {
     const int N = B * T;
     if (N == 0) return hipSuccess;
+    // a handful of tokens (latency regime): one block per token, nothing staged
+    static const bool no_token_form = getenv("MVQ_NO_TOKEN_RVQ") != nullptr;      // A/B measurements
+    if (N <= 256 && D % 4 == 0 && D <= 128 && !no_token_form) {
+        hipLaunchKernelGGL(rvq_ema_forward_token_kernel, dim3(N), dim3(256), 0, s, z, books, q_out, idx_out, B, D, T, nb, K, update_residual);
+        return hipGetLastError();
+    }
     // many tokens: the MFMA form (one block per 32 tokens, >= 32 blocks); few tokens: the scalar form with 8 tokens per block
     // (more blocks, and the codebook staging rather than the arithmetic is what a short chunk waits for)
     const size_t lds_mfma = ((size_t)RVQ_KH * (D + 1) + RVQ_KH + 2 * (size_t)D * 32 + 8 * 32 + 2 * 32) * sizeof(float);

@@ -18,6 +18,7 @@ the decoder input (training config) is not part of this round.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -162,10 +163,16 @@ class ResidualUnit(nn.Module):
         self.block = nn.Sequential(Snake1d(dim), WNConv1d(dim, dim, 7, dilation=dilation, padding=pad),
                                    Snake1d(dim), WNConv1d(dim, dim, 1))
 
-    # Wide units (C >= 192, several 128-row tiles per time tile) take their input Snake from the producer's dual output
-    # instead of re-evaluating it once per row tile while staging.
+    # Units with C >= 96 take their input Snake from the producer's dual output: the wide ones (C >= 192, several 128-row
+    # tiles per time tile) would otherwise re-evaluate it once per row tile while staging, and the fused ones (C = 96, 128)
+    # then stage their 7-tap conv with LDS-DMA (no Snake on load, no halo re-evaluation): measured +3 % at C = 128, +0.6 % at
+    # C = 96.  At C = 64 the extra Snake of the dual output and the second output tensor cost more than the staging saves
+    # (89.7-96.2 vs 99.2-106.9 TFLOP/s, gpurun_out/r3e), so those units keep Snake-on-load.
+    # MVQ_RU_PRESNAKED=0 / =all: never / always for the fused widths (A/B runs).
+    PRESNAKED_MIN_C = {"0": 129, "all": 1}.get(os.environ.get("MVQ_RU_PRESNAKED", ""), 65)
+
     def wants_presnaked(self) -> bool:
-        return self.block[1].cin > 128
+        return self.block[1].cin >= self.PRESNAKED_MIN_C
 
     def run(self, x, alpha_next=None, x_snaked=None, alpha_dual=None, tvalid=0):
         c7, c1 = self.block[1], self.block[3]
@@ -221,7 +228,9 @@ class Encoder(nn.Module):
     @torch.no_grad()
     def forward(self, x):
         n = len(self.block)
-        h, hs = self.block[0].run(x), None
+        a1 = self.block[1].first_alpha()                            # first unit wants a pre-snaked input: dual output of the 1 -> 64 conv
+        out = self.block[0].run(x, alpha_dual=a1)
+        h, hs = out if a1 is not None else (out, None)
         for i in range(1, n - 2):
             last = i == n - 3
             nxt = None if last else self.block[i + 1].first_alpha()   # next block's first unit wants a pre-snaked input?

@@ -90,3 +90,60 @@ def allreduce_grads(params, local_items: int, group=None) -> None:
         k = p.grad.numel()
         p.grad.copy_(flat[off:off + k].view_as(p.grad))
         off += k
+
+
+class Ranks:
+    """What ``bring_up`` returns: the process group the data path uses and how it came up."""
+
+    def __init__(self, dist, group, backend, rccl_ranks, local_rank):
+        self.dist, self.group, self.backend, self.rccl_ranks, self.local_rank = dist, group, backend, rccl_ranks, local_rank
+
+    @property
+    def reduce_device(self):
+        return torch.device("cuda", self.local_rank) if self.backend == "nccl" else torch.device("cpu")
+
+    def barrier(self):
+        if self.dist is None:
+            return
+        if self.backend == "nccl":
+            self.dist.barrier(group=self.group, device_ids=[self.local_rank])
+        else:
+            self.dist.barrier()
+
+
+def fatal(rank, msg, code=3):
+    """A rank that cannot continue says why and leaves at once (torch.distributed.run then stops the other ranks) -- it never
+    sits in a collective the others will not reach."""
+    import os
+    import sys
+    print(f"[rank {rank}] FATAL: {msg}", file=sys.stderr, flush=True)
+    os._exit(code)
+
+
+def bring_up(rank: int, world: int, local_rank: int, backend: str = "nccl", one_device: bool = False,
+             rehearse_failure: bool = False) -> Ranks:
+    """One process per GPU under torch.distributed.run.  The rendezvous goes over gloo (host only: it cannot fail for GPU
+    reasons and gives every rank a way to learn that a peer died).  The data-path group is RCCL (``"nccl"`` on ROCm) and has
+    to PROVE itself: one all-reduce of ones must return the world size on every rank; anything else is fatal -- there is no
+    silent fallback to gloo.  gloo carries the collectives only in the explicit one-device rehearsal (``one_device``: every
+    rank on cuda:0, which RCCL refuses) or when the caller asks for ``backend="gloo"``."""
+    import datetime
+    import sys
+    import torch.distributed as dist
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+    use_gloo = (one_device and not rehearse_failure) or backend == "gloo"
+    if world > 1 and not one_device and backend == "gloo":
+        print(f"[rank {rank}] backend gloo with distinct devices: collectives go over the host", file=sys.stderr)
+    if use_gloo:
+        return Ranks(dist, None, "gloo (one-device rehearsal)" if one_device else "gloo", None, local_rank)
+    try:
+        grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+        probe = torch.ones(1, device=torch.device("cuda", local_rank))
+        dist.all_reduce(probe, group=grp)
+        torch.cuda.synchronize()
+        n = int(round(float(probe.item())))
+    except Exception as ex:                                    # noqa: BLE001 -- whatever RCCL raises is fatal here
+        fatal(rank, f"RCCL group did not come up ({type(ex).__name__}: {ex})")
+    if n != world:
+        fatal(rank, f"RCCL all-reduce of ones returned {n}, expected {world}")
+    return Ranks(dist, grp, "nccl", n, local_rank)

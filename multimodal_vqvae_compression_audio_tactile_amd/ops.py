@@ -125,12 +125,14 @@ def residual_unit_kernel_name(c, dil) -> str:
     return buf.value.decode()
 
 
-def residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, alpha_dual=None, tvalid=0):
-    """The single-launch form (C in {64, 96, 128})."""
+def residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, alpha_dual=None, tvalid=0, x_snaked=None):
+    """The single-launch form (C in {64, 96, 128}).  x_snaked = snake_a(x) (the producer's dual output): staged as is."""
     B, C, T = x.shape
     y = torch.empty_like(x)
     y2 = torch.empty_like(x) if alpha_dual is not None else None
-    check(_lib.lib().mvq_residual_unit_padded_f32(x.data_ptr(), None, w7p.data_ptr(), _p(b7), alpha_a.data_ptr(),
+    if x_snaked is not None and x_snaked.shape != x.shape:
+        raise MvqError("residual_unit: x_snaked must have the shape of x")
+    check(_lib.lib().mvq_residual_unit_padded_f32(x.data_ptr(), _p(x_snaked), w7p.data_ptr(), _p(b7), alpha_a.data_ptr(),
                                                   alpha_b.data_ptr(), w1p.data_ptr(), _p(b1), _p(alpha_next), y.data_ptr(),
                                                   _p(y2), _p(alpha_dual), None, B, C, T, dil, int(tvalid), _stream()),
           "mvq_residual_unit_f32")
@@ -145,7 +147,7 @@ def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x
     x = _dev(x, "x")
     B, C, T = x.shape
     if _lib.lib().mvq_residual_unit_scratch_floats(B, C, T, dil) == 0:
-        return residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next, alpha_dual, tvalid)
+        return residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next, alpha_dual, tvalid, x_snaked)
     if x_snaked is not None:
         h = conv1d(x_snaked, w7p, C, 7, bias=b7, dil=dil, pad=3 * dil, alpha_out=alpha_b, tvalid=tvalid)
     else:
@@ -329,8 +331,8 @@ def align_xcorr(ref, est, max_shift=200):
 
 
 def align_xcorr_batch(ref, est, max_shift=200):
-    """Best shift per item for ref[B,T] / est[B,T] (equal lengths): B launches on the stream, NO host sync; returns the
-    int32 device tensor of shifts (read it once for the whole batch)."""
+    """Best shift per item for ref[B,T] / est[B,T] (equal lengths): ONE launch pair for the whole batch (grid dimension =
+    item), NO host sync; returns the int32 device tensor of shifts."""
     ref = _dev(ref, "ref"); est = _dev(est, "est")
     if ref.shape != est.shape or ref.dim() != 2:
         raise MvqError("align_xcorr_batch: ref and est must both be [B, T]")
@@ -339,11 +341,24 @@ def align_xcorr_batch(ref, est, max_shift=200):
     corr = torch.empty(B, n, device=ref.device, dtype=torch.float32)
     scratch = torch.empty(B, n, device=ref.device, dtype=torch.int32)
     best = torch.zeros(B, device=ref.device, dtype=torch.int32)
-    f = _lib.lib().mvq_align_xcorr_f32
-    for b in range(B):
-        check(f(ref.data_ptr() + 4 * b * T, est.data_ptr() + 4 * b * T, T, max_shift, corr.data_ptr() + 4 * b * n,
-                scratch.data_ptr() + 4 * b * n, best.data_ptr() + 4 * b, _stream()), "mvq_align_xcorr_f32")
+    check(_lib.lib().mvq_align_xcorr_batch_f32(ref.data_ptr(), est.data_ptr(), B, T, max_shift, corr.data_ptr(),
+                                               scratch.data_ptr(), best.data_ptr(), _stream()), "mvq_align_xcorr_batch_f32")
     return best
+
+
+def resample_ragged(x, kern, off, length, orig, newf, width, lout_pitch):
+    """Rows x[b, off[b] : off[b] + length[b]] resampled by the filter bank kern[newf, 2*width + orig] in one launch.
+    off / length: int32 device tensors [B].  -> (y[B, lout_pitch] zero past each row's output length, lout int32 [B])."""
+    x = _dev(x, "x")
+    if x.dim() != 2 or off.dtype != torch.int32 or length.dtype != torch.int32 or not off.is_cuda or not length.is_cuda:
+        raise MvqError("resample_ragged: x must be [B, L]; off / length int32 HIP tensors")
+    B, L = x.shape
+    y = torch.empty(B, lout_pitch, device=x.device, dtype=torch.float32)
+    lout = torch.empty(B, device=x.device, dtype=torch.int32)
+    check(_lib.lib().mvq_resample_ragged_f32(x.data_ptr(), kern.data_ptr(), y.data_ptr(), off.data_ptr(), length.data_ptr(),
+                                             lout.data_ptr(), B, L, lout_pitch, orig, newf, width, kern.shape[1], _stream()),
+          "mvq_resample_ragged_f32")
+    return y, lout
 
 
 # ---------------------------------------------------------------------------------- backward (row f1)

@@ -120,63 +120,58 @@ static inline float om_gelu(float x)
     return (0.5f * x) * (1.0f + om_erf(x * RSQRT2));
 }
 
-/* ---- sin(y)^2 directly: period pi, even in the reduced argument -> one polynomial, no quadrant logic --------
- *   n = rint(y/pi) ; r = y - n*pi (3-term Cody-Waite) in [-pi/2, pi/2] ; u = r*r ;
- *   sin^2 r = u - u^2/3 + 2u^3/45 - u^4/315 + ...  (Taylor, 9 terms: truncation < 3e-9 at |r| = pi/2)            */
-static inline float om_sin2(float y)
+/* ---- sin(pi*t)^2, t in TURNS of the half period: n = rint(t), f = t - n (exact in fp32, |f| <= 0.5), v = f*f,
+ *   sin(pi f)^2 = v*(c1 + c2 v + ... + c9 v^8), c_k = (-1)^(k+1) 2^(2k-1) pi^(2k) / (2k)!  (truncation < 2e-9 at |f| = 0.5) */
+static inline float om_sin2_turns(float t)
 {
-    const float INV_PI = 0.318309886183790672f;
-    const float PI_1 = 3.140625f;                  /* pi split: 8 significant bits */
-    const float PI_2 = 9.67502593994140625e-4f;
-    const float PI_3 = 1.509957990978376e-7f;
-    float n = rintf(y * INV_PI);
-    float r = om_fma(-n, PI_1, y);
-    r = om_fma(-n, PI_2, r);
-    r = om_fma(-n, PI_3, r);
-    float u = r * r;
-    float p = om_fma(u, 2.04724070e-11f, -1.56613913e-09f);
-    p = om_fma(u, p, 9.39683479e-08f);
-    p = om_fma(u, p, -4.27555983e-06f);
-    p = om_fma(u, p, 1.41093474e-04f);
-    p = om_fma(u, p, -3.17460317e-03f);
-    p = om_fma(u, p, 4.44444444e-02f);
-    p = om_fma(u, p, -3.33333333e-01f);
-    p = om_fma(u, p, 1.0f);
-    return u * p;
+    float n = rintf(t);
+    float f = t - n;
+    float v = f * f;
+    float p = om_fma(v, 0.018191421404480934f, -0.14100298285484314f);
+    p = om_fma(v, p, 0.8571953773498535f);
+    p = om_fma(v, p, -3.951768159866333f);
+    p = om_fma(v, p, 13.213128089904785f);
+    p = om_fma(v, p, -30.1223201751709f);
+    p = om_fma(v, p, 42.72840881347656f);
+    p = om_fma(v, p, -32.469696044921875f);
+    p = om_fma(v, p, 9.869604110717773f);
+    return v * p;
 }
 
-/* Snake1d: x + (alpha + 1e-9)^-1 * sin(alpha*x)^2   [upstream dac/nn/layers.py snake()] */
+/* Snake1d: x + (alpha + 1e-9)^-1 * sin(alpha*x)^2   [upstream dac/nn/layers.py snake()];  alpha*x = pi * t with
+ * t = x * (alpha * (1/pi)) -- the phase rounds twice here where torch's alpha*x rounds once (same order of error). */
 static inline float om_snake(float x, float alpha)
 {
+    const float INV_PI = 0.318309886183790672f;
     float inv = 1.0f / (alpha + 1e-9f);
-    return om_fma(inv, om_sin2(alpha * x), x);
+    float c = alpha * INV_PI;
+    return om_fma(inv, om_sin2_turns(x * c), x);
 }
 
-/* sin(y) with the period-pi reduction of om_sin2: n = rint(y/pi), r = y - n*pi in [-pi/2, pi/2],
- * sin(y) = (-1)^n * (r - r^3/3! + ... - r^15/15!)   (one odd polynomial, sign from the parity of n) */
-static inline float om_sin_pi(float y)
+/* sin(pi*t): n = rint(t), f = t - n exact, f*(d0 + d1 v + ... + d7 v^7), d_k = (-1)^k pi^(2k+1)/(2k+1)!, sign from n's parity */
+static inline float om_sin_turns(float t)
 {
-    float n = rintf(y * 0.318309886183790672f);
-    float r = om_fma(-n, 3.140625f, y);
-    r = om_fma(-n, 9.67502593994140625e-4f, r);
-    r = om_fma(-n, 1.509957990978376e-7f, r);
-    float u = r * r;
-    float p = om_fma(u, -7.64716373e-13f, 1.60590438e-10f);
-    p = om_fma(u, p, -2.50521084e-08f);
-    p = om_fma(u, p, 2.75573192e-06f);
-    p = om_fma(u, p, -1.98412698e-04f);
-    p = om_fma(u, p, 8.33333333e-03f);
-    p = om_fma(u, p, -1.66666667e-01f);
-    float s = om_fma(r * u, p, r);
+    float n = rintf(t);
+    float f = t - n;
+    float v = f * f;
+    float p = om_fma(v, -2.191535349993501e-05f, 0.0004663027939386666f);
+    p = om_fma(v, p, -0.00737043097615242f);
+    p = om_fma(v, p, 0.08214588463306427f);
+    p = om_fma(v, p, -0.5992645025253296f);
+    p = om_fma(v, p, 2.550163984298706f);
+    p = om_fma(v, p, -5.167712688446045f);
+    p = om_fma(v, p, 3.1415927410125732f);
+    float s = f * p;
     return ((int)n & 1) ? -s : s;
 }
 
 /* d snake(x)/dx = 1 + (alpha/(alpha+1e-9)) * sin(2*alpha*x)   (backward of Snake1d) */
 static inline float om_dsnake(float x, float alpha)
 {
+    const float INV_PI = 0.318309886183790672f;
     float inv = 1.0f / (alpha + 1e-9f);
-    float ax = alpha * x;
-    return om_fma(alpha * inv, om_sin_pi(ax + ax), 1.0f);
+    float t = x * (alpha * INV_PI);
+    return om_fma(alpha * inv, om_sin_turns(t + t), 1.0f);
 }
 
 #endif /* ORACLE_DET_MATH_H */

@@ -477,8 +477,8 @@ void orc_attention(const float* Q, const float* Kx, const float* V, float* ctx,
 void orc_gelu(const float* x, float* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = om_gelu(x[i]); }
 void orc_tanh(const float* x, float* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = om_tanh(x[i]); }
 void orc_sin(const float* x, float* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = om_sin(x[i]); }
-void orc_sin_pi(const float* x, float* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = om_sin_pi(x[i]); }
-void orc_sin2(const float* x, float* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = om_sin2(x[i]); }
+void orc_sin_turns(const float* x, float* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = om_sin_turns(x[i]); }
+void orc_sin2_turns(const float* x, float* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = om_sin2_turns(x[i]); }
 void orc_exp(const float* x, float* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = om_exp(x[i]); }
 void orc_erf(const float* x, float* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = om_erf(x[i]); }
 

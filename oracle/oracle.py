@@ -134,8 +134,8 @@ def _unary(name, x):
 def gelu(x): return _unary("orc_gelu", x)
 def tanh(x): return _unary("orc_tanh", x)
 def sin(x): return _unary("orc_sin", x)
-def sin2(x): return _unary("orc_sin2", x)
-def sin_pi(x): return _unary("orc_sin_pi", x)
+def sin2_turns(t): return _unary("orc_sin2_turns", t)     # sin(pi t)^2
+def sin_turns(t): return _unary("orc_sin_turns", t)       # sin(pi t)
 def exp(x): return _unary("orc_exp", x)
 def erf(x): return _unary("orc_erf", x)
 

@@ -86,6 +86,35 @@ def test_gradient_allreduce_equals_global_batch(tmp_path):
     assert torch.allclose(g0["w"], w.grad, rtol=1e-5, atol=1e-7) and torch.allclose(g0["b"], b.grad, rtol=1e-5, atol=1e-7)
 
 
+def _bringup_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from multimodal_vqvae_compression_audio_tactile_amd import dist as mdist
+    ranks = mdist.bring_up(rank, world, 0, backend="gloo")      # the explicit host-collective mode (no GPU here)
+    assert ranks.backend == "gloo" and ranks.group is None and ranks.rccl_ranks is None and ranks.reduce_device.type == "cpu"
+    # the padded two-stage gather tools/corpus_eval.py uses for its per-rank metric vectors (uneven shards)
+    vals = [float(10 * rank + i) for i in range(3 + rank)]
+    head = torch.tensor([len(vals)], dtype=torch.float64)
+    heads = [torch.zeros_like(head) for _ in range(world)]
+    ranks.dist.all_gather(heads, head, group=ranks.group)
+    nmax = int(max(h[0].item() for h in heads))
+    body = torch.zeros(nmax, dtype=torch.float64); body[:len(vals)] = torch.tensor(vals, dtype=torch.float64)
+    bodies = [torch.zeros_like(body) for _ in range(world)]
+    ranks.dist.all_gather(bodies, body, group=ranks.group)
+    got = [b[:int(h[0].item())].tolist() for h, b in zip(heads, bodies)]
+    torch.save(got, os.path.join(out_dir, f"gather_{rank}.pt"))
+    ranks.barrier()
+    ranks.dist.destroy_process_group()
+
+
+def test_bring_up_and_metric_gather(tmp_path):
+    """dist.bring_up in its gloo mode + the gather of per-rank metric lists (BASELINE.json configs[3]'s only exchange)."""
+    world = 2
+    mp.start_processes(_bringup_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    want = [[0.0, 1.0, 2.0], [10.0, 11.0, 12.0, 13.0]]
+    assert torch.load(tmp_path / "gather_0.pt") == want and torch.load(tmp_path / "gather_1.pt") == want
+
+
 def test_sharding_covers_every_segment_once():
     from multimodal_vqvae_compression_audio_tactile_amd import dist as mdist
     for n in (0, 1, 7, 8, 1003):

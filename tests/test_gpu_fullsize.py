@@ -106,6 +106,32 @@ def test_edge_cases(model, orc, dev):
         assert mdl.decode(z).shape == (2, 1, 23992)
 
 
+def test_dac_rate_sweep_full_size_against_oracle(orc, dev):
+    """``DAC_NQ_LIST = [1, 4, 8, 16, 32]`` of Evaluation/compare_dacvsproposal_3.5_eval.py:75, the rate-scalable DAC-24 kHz
+    baseline of its eval_dac24_ratescalable (``mdl.encode(t, n_quantizers=n_q)`` / ``mdl.decode(z)``, ...:444-446): one full
+    24 000-sample segment per sweep point -- codes, latents, z and the decoded waveform bit-exact against the oracle; the
+    encoder runs once in the oracle (it does not depend on n_q) and the decode is checked at the 32-book point."""
+    import multimodal_vqvae_compression_audio_tactile_amd as mvq
+    from multimodal_vqvae_compression_audio_tactile_amd import synth
+    sd = synth.dac_state(7)
+    sdn = _np(sd)
+    mdl = mvq.DAC(); mdl.load_state_dict(sd, strict=True); mdl = mdl.to(dev).eval()
+    x = synth.tactile_segments(1, seed=33)
+    ze = orc.dac_encoder(sdn, x.numpy(), prefix="encoder.")
+    assert ze.shape == (1, 1024, 75)
+    for n_q in (1, 4, 8, 16, 32):
+        want_zq, want_codes, want_lat, _, _ = orc.dac_quantizer(sdn, ze, n_q, prefix="quantizer.")
+        z, codes, lat, _, _ = mdl.encode(x.to(dev), n_quantizers=n_q)
+        assert codes.shape == (1, n_q, 75) and lat.shape == (1, 8 * n_q, 75)
+        assert np.array_equal(codes.cpu().numpy(), want_codes)
+        assert np.array_equal(lat.cpu().numpy(), want_lat)
+        assert np.array_equal(z.cpu().numpy(), want_zq)
+        if n_q == 32:                                             # (one oracle decode: 83 GFLOP of scalar fma chains on the host)
+            y = mdl.decode(z)
+            want_y = orc.dac_decoder(sdn, want_zq, prefix="decoder.")
+            assert y.shape == (1, 1, 23992) and np.array_equal(y.cpu().numpy(), want_y)
+
+
 def test_hipgraph_replay_is_bit_equal_to_eager(model, dev):
     """graphs.GraphedCall (one hipGraph per call, B = 1 latency regime): a replay -- also on NEW input values copied into the
     captured buffers -- returns exactly what the eager launch sequence returns, for encode_latents (two-stream fork inside

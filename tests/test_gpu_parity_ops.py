@@ -146,6 +146,7 @@ def test_weight_norm_bit_exact(orc, dev):
 
 @pytest.mark.parametrize("B,T,nb,K,use", [(6, 16, 3, 128, None), (2, 11, 10, 128, 7), (3, 16, 8, 512, None),
                                          (1, 75, 4, 256, 2), (5, 16, 1, 512, None), (2, 1, 2, 64, None),
+                                         (20, 16, 3, 512, None), (9, 75, 2, 256, 1),   # 257..1023 tokens: 8 tokens per block (<= 256: one block per token)
                                          (40, 103, 2, 512, None),    # >= 1024 tokens: the MFMA form of the search
                                          (64, 16, 8, 512, None), (70, 16, 3, 128, 2), (67, 16, 10, 256, None), (14, 75, 2, 512, None)])
 def test_rvq_ema_forward_bit_exact(B, T, nb, K, use, orc, dev):
@@ -166,7 +167,7 @@ def test_rvq_ema_forward_ties_pick_lowest_index(orc, dev):
     D, K = 96, 512
     book = r.standard_normal((K, D)).astype(np.float32) / math.sqrt(D)
     book[300] = book[17]; book[499] = book[17]; book[40] = book[17]     # exact duplicates
-    for T in (5, 1100):                                                  # scalar form / MFMA form (>= 1024 tokens)
+    for T in (5, 300, 1100):                                             # token form / 8-token scalar form / MFMA form
         z = np.repeat(book[17][None, :, None], T, axis=2).astype(np.float32)   # query == that code
         q, idx = ops.rvq_ema_forward(_t(z, dev), _t(book[None], dev), return_indices=True)
         _, want = orc.rvq_ema_forward(z, [book])

@@ -17,11 +17,18 @@ def test_det_math_accuracy(orc):
     r = np.random.default_rng(0)
     x = r.uniform(-60, 60, 400000).astype(np.float32)
     assert np.abs(orc.sin(x) - np.sin(x.astype(np.float64))).max() < 1.5e-7
-    x = r.uniform(-200, 200, 400000).astype(np.float32)
-    assert np.abs(orc.sin2(x) - np.sin(x.astype(np.float64)) ** 2).max() < 2.5e-7       # Snake's sin^2 (period-pi form)
-    assert np.abs(orc.sin_pi(x) - np.sin(x.astype(np.float64))).max() < 2.5e-7            # Snake backward's sin
-    xs = r.uniform(-3, 3, 100000).astype(np.float32)
-    assert np.abs(orc.sin2(xs) - np.sin(xs.astype(np.float64)) ** 2).max() < 2.5e-7
+    # Snake's sin^2 and the Snake backward's sin, in turns: the fp32 phase t is exact input here, so the bound is the
+    # polynomial's + rounding (the phase t = x * (alpha/pi) itself rounds like the reference's own alpha*x product)
+    t = r.uniform(-64, 64, 400000).astype(np.float32)
+    assert np.abs(orc.sin2_turns(t) - np.sin(np.pi * t.astype(np.float64)) ** 2).max() < 2.5e-7
+    assert np.abs(orc.sin_turns(t) - np.sin(np.pi * t.astype(np.float64))).max() < 2.5e-7
+    ts = r.uniform(-1, 1, 100000).astype(np.float32)
+    assert np.abs(orc.sin2_turns(ts) - np.sin(np.pi * ts.astype(np.float64)) ** 2).max() < 2.5e-7
+    # the whole Snake against float64 on activation-scale inputs: x + sin(alpha x)^2 / alpha
+    xs = r.uniform(-6, 6, (1, 50, 4000)).astype(np.float32)
+    al = r.uniform(0.3, 3.0, 50).astype(np.float32)
+    want = xs.astype(np.float64) + np.sin(al[None, :, None].astype(np.float64) * xs) ** 2 / (al[None, :, None].astype(np.float64) + 1e-9)
+    assert np.abs(orc.snake(xs, al) - want).max() < 2e-6
     x = r.uniform(-87, 20, 400000).astype(np.float32)
     ref = np.exp(x.astype(np.float64))
     assert (np.abs(orc.exp(x) - ref) / ref).max() < 2.5e-7

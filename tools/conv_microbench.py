@@ -52,7 +52,11 @@ for (name, kind, cin, cout, ks, st, dil, tin, ai, res, ao, count) in layers:
         w1 = ops.pack_conv1d(torch.randn(cout, cin, 1, device=dev) / math.sqrt(cin))
         b7 = torch.randn(cout, device=dev); b1 = torch.randn(cout, device=dev)
         aa = torch.rand(cin, device=dev) + 0.5; ab = torch.rand(cin, device=dev) + 0.5
-        f = lambda: ops.residual_unit(x, w7, b7, aa, ab, w1, b1, dil)
+        if os.environ.get("MVQ_MB_RU", "presnaked") == "presnaked":     # the production call: pre-snaked input + dual output
+            xs = torch.randn_like(x); a2 = torch.rand(cin, device=dev) + 0.5
+            f = lambda: ops.residual_unit(x, w7, b7, aa, ab, w1, b1, dil, x_snaked=xs, alpha_dual=a2)
+        else:                                                             # round-2 call: Snake on load, single output
+            f = lambda: ops.residual_unit(x, w7, b7, aa, ab, w1, b1, dil)
         flops = 2.0 * cin * cout * 8 * Tx * Bx
         kname = "       residual_unit_kernel"
     elif kind == "t":

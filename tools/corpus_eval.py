@@ -42,18 +42,22 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--books", type=int, default=8)
     ap.add_argument("--embed", type=int, default=512)
+    ap.add_argument("--backend", default="nccl", help="nccl == RCCL (default); gloo only for the one-device rehearsal")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="bring the RCCL group up and run the gather even with one rank (executes the RCCL path on a one-GPU box)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if os.environ.get("MVQ_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("gloo")        # the only exchange is one gather of per-rank metric lists (host objects)
-
     import multimodal_vqvae_compression_audio_tactile_amd as mvq
     from multimodal_vqvae_compression_audio_tactile_amd import dist as mdist, synth
+    dist, ranks = None, None
+    if world > 1 or args.force_collectives:
+        # BASELINE.json configs[3]: "... frame-sharded across 8 MI355X via RCCL".  Ranks on distinct devices bring up an RCCL
+        # group that must pass the all-reduce probe (fatal otherwise, no fallback); gloo only in the one-device rehearsal.
+        ranks = mdist.bring_up(rank, world, local, backend=args.backend, one_device=os.environ.get("MVQ_BENCH_ONE_DEVICE") == "1")
+        dist = ranks.dist
 
     net = mvq.build_proposed(synth.proposed_model_state(7, rvq_books=args.books, rvq_embed=args.embed),
                              rvq_books=args.books, rvq_embed=args.embed, device=dev)
@@ -103,15 +107,31 @@ def main():
     out = {"rank": rank, "n": len(st_vals), "st": st_vals, "ps": ps_vals, "t_load": t_load, "t_fwd": t_fwd, "t_met": t_met}
     parts = [out]
     if dist:
-        parts = [None] * world
-        dist.all_gather_object(parts, out)
+        # the one exchange of this config: per-rank metric vectors, padded to the longest shard, all-gathered on the device
+        # over RCCL (three scalars + two float64 vectors per rank), then trimmed by the gathered counts
+        dev_r = ranks.reduce_device
+        head = torch.tensor([len(st_vals), t_load, t_fwd, t_met], dtype=torch.float64, device=dev_r)
+        heads = [torch.zeros_like(head) for _ in range(world)]
+        dist.all_gather(heads, head, group=ranks.group)
+        nmax = int(max(h[0].item() for h in heads))
+        body = torch.zeros(2, max(nmax, 1), dtype=torch.float64, device=dev_r)
+        body[0, :len(st_vals)] = torch.tensor(st_vals, dtype=torch.float64)
+        body[1, :len(ps_vals)] = torch.tensor(ps_vals, dtype=torch.float64)
+        bodies = [torch.zeros_like(body) for _ in range(world)]
+        dist.all_gather(bodies, body, group=ranks.group)
+        parts = []
+        for r_, (h, bdy) in enumerate(zip(heads, bodies)):
+            n_ = int(h[0].item())
+            parts.append({"rank": r_, "n": n_, "st": bdy[0, :n_].cpu().tolist(), "ps": bdy[1, :n_].cpu().tolist(),
+                          "t_load": float(h[1]), "t_fwd": float(h[2]), "t_met": float(h[3])})
     if rank == 0:
         st = np.array([v for p in parts for v in p["st"]], np.float64); ps = np.array([v for p in parts for v in p["ps"]], np.float64)
         n = int(st.size)
         tps = 75.0
         kbps = tps * args.books * math.log2(args.embed) / 1000.0
         res = {"config": "synthetic corpus, round-robin segment sharding", "clips": args.clips, "segments": n_seg, "n": n,
-               "n_gpus": world, "books": args.books, "embed": args.embed, "tps": tps, "kbps": kbps,
+               "n_gpus": world, "collective_backend": ranks.backend if ranks else None, "rccl_ranks": ranks.rccl_ranks if ranks else None,
+               "books": args.books, "embed": args.embed, "tps": tps, "kbps": kbps,
                "compression_ratio": PCM_KBPS_TACT_ORIG / kbps,
                "stsim_mean": float(st.mean()), "stsim_ci95": 1.96 * float(st.std(ddof=0)) / max(1.0, math.sqrt(n)),
                "psnr_mean": float(ps.mean()), "psnr_ci95": 1.96 * float(ps.std(ddof=0)) / max(1.0, math.sqrt(n)),
@@ -122,7 +142,7 @@ def main():
                        "and the sharding are what is exercised"}
         print(json.dumps(res), flush=True)
     if dist:
-        dist.barrier(); dist.destroy_process_group()
+        ranks.barrier(); dist.destroy_process_group()
 
 
 if __name__ == "__main__":
