@@ -409,6 +409,10 @@ def main():
             line["path_tflops"] = seg_s * gf * 1e-3 / world            # per GPU, algorithmic
         if unprof_ms is not None:
             line["ms_per_step_without_kernel_events"] = unprof_ms     # rank 0, untimed extra steps after the measured region
+        ms_ = torch.cuda.memory_stats(dev)
+        line["device_memory"] = {"peak_allocated_GB": ms_.get("allocated_bytes.all.peak", 0) / 1e9,
+                                 "peak_reserved_GB": ms_.get("reserved_bytes.all.peak", 0) / 1e9,
+                                 "alloc_retries": ms_.get("num_alloc_retries", 0)}
         if train and phase_ev:
             acc = defaultdict(float)
             for name, e0, e1 in phase_ev:

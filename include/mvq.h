@@ -324,6 +324,14 @@ int mvq_conv_transpose1d_padded_f32(const float* x, const float* wp, const float
                                     const float* alpha_out, float* y, float* y2, const float* alpha2,
                                     int batch, int cin, int tin, int cout, int stride, int pad, int tout_rows, int tvalid,
                                     void* stream);
+/* The same with torch's ``output_padding`` (0 <= output_padding < stride, <= pad): the natural row length grows by that many
+ * samples at the END of each row -- the same sum evaluated there.  For the DecoderBlock variant with
+ * ``output_padding = stride % 2`` (believed to be upstream DAC's repository head; release 1.0.0 -- the default of this
+ * package and of the oracle -- passes none): 75 tokens then decode to 24 000 samples instead of 23 992. */
+int mvq_conv_transpose1d_op_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                                const float* alpha_out, float* y, float* y2, const float* alpha2,
+                                int batch, int cin, int tin, int cout, int stride, int pad, int output_padding, int tout_rows,
+                                int tvalid, void* stream);
 
 /* Polyphase sinc resampler: torchaudio.transforms.Resample(orig, new) as the reference
  * calls it on every file (Training/compare_dacvsproposal_5.py:110-113, Evaluation/dac_vcpwq_proposed6_latency.py:151-156).

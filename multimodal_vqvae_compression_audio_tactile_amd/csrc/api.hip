@@ -388,14 +388,26 @@ int mvq_conv_transpose1d_padded_f32(const float* x, const float* wp, const float
                                     int batch, int cin, int tin, int cout, int stride, int pad, int tout_rows, int tvalid,
                                     void* stream)
 {
+    return mvq_conv_transpose1d_op_f32(x, wp, bias, alpha_in, alpha_out, y, y2, alpha2, batch, cin, tin, cout, stride, pad, 0,
+                                       tout_rows, tvalid, stream);
+}
+
+int mvq_conv_transpose1d_op_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                                const float* alpha_out, float* y, float* y2, const float* alpha2,
+                                int batch, int cin, int tin, int cout, int stride, int pad, int output_padding, int tout_rows,
+                                int tvalid, void* stream)
+{
     if (batch < 0 || cin <= 0 || cout <= 0 || tin < 0 || stride <= 0 || pad < 0)
         return fail(MVQ_EINVAL, "conv_transpose1d: bad shape");
-    const int tnat = (tin - 1) * stride - 2 * pad + 2 * stride;
+    /* torch: output_padding < stride; the polyphase form reaches `pad` columns past the un-padded length, so <= pad as well */
+    if (output_padding < 0 || output_padding >= stride || output_padding > pad)
+        return fail(MVQ_EINVAL, "conv_transpose1d: output_padding %d outside [0, min(stride - 1, pad)]", output_padding);
+    const int tnat = (tin - 1) * stride - 2 * pad + 2 * stride + output_padding;
     /* tout_rows: length of the output rows (0 = the natural length).  Shorter than natural: the input carries a zero tail and
      * only its true outputs are wanted.  Up to `pad` longer (the polyphase form visits those columns too): rows padded to a
      * multiple of 4, columns >= tvalid zeroed. */
     const int tout = tout_rows > 0 ? tout_rows : tnat;
-    if (tout > tnat + pad || tvalid < 0 || tvalid > tout || (tout > tnat && (tvalid == 0 || tvalid > tnat)))
+    if (tout > tnat - output_padding + pad || tvalid < 0 || tvalid > tout || (tout > tnat && (tvalid == 0 || tvalid > tnat)))
         return fail(MVQ_EINVAL, "conv_transpose1d: tout_rows %d / tvalid %d inconsistent with the natural length %d", tout, tvalid, tnat);
     if (batch == 0 || tin == 0 || tout <= 0) return MVQ_OK;
     if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv_transpose1d: null tensor");

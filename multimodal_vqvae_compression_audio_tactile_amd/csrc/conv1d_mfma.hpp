@@ -84,10 +84,8 @@ struct ConvArgs {
     int name_len;
 };
 
-// k-steps per operand-read group (see conv1d_mfma_body).  Double-buffered groups (the reads of group g+1 are in flight
-// during the MFMAs of group g) get 2 x 16 operand registers, single-buffered ones 28; a divisor of the chunk's k-step count is
-// preferred (no ragged last group).  A/B builds: -DMVQ_KGROUP=n fixes the group size (1 = one k-step per group, the round-2
-// schedule), -DMVQ_KPREFETCH=0 selects the single-buffered form.
+// k-steps per operand-read group (see conv1d_mfma_body): 1 by default.  A/B builds: -DMVQ_KGROUP=n fixes the group size,
+// -DMVQ_KPREFETCH=0 selects the single-buffered form (reads of a group, wait, its MFMAs).
 #ifndef MVQ_KPREFETCH
 #define MVQ_KPREFETCH 1
 #endif
@@ -223,7 +221,11 @@ struct ConvTile {
                 const bool ok = g >= 0 && g < Tin;
                 f32x4 q = xv[u];
                 if (!ok) q = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#if defined(MVQ_EXP) && (MVQ_EXP & 8)
+                if (false) {
+#else
                 if (snake_in) {
+#endif
                     const float al = Al[ci0 + cl], inv = Al[Cin + ci0 + cl];
                     q.x = det_snake(q.x, al, inv); q.y = det_snake(q.y, al, inv);
                     q.z = det_snake(q.z, al, inv); q.w = det_snake(q.w, al, inv);
@@ -338,10 +340,14 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     // one chunk of MFMAs out of LDS buffer `buf`; operands of k-step s+1 are fetched before the MFMAs of step s
     // (Skipping the MFMAs of column subtiles that lie past the end of the row was measured: +0.3 % -- the block lasts as long
     // as its busiest wave.  Rows with a mostly empty last tile are split into two launches instead: conv_tail_width.)
-    // Operand reads are issued in GROUPS of KG k-steps, one group ahead of the MFMAs that consume them: a wave's stream is
-    // [reads of group g+1][MFMAs of group g] with one lgkmcnt wait per group instead of one per k-step.  Measured on the box
-    // (tools/mfma_probe.hip, profiles/r03_mfma_probe.jsonl): an LDS-fed 32x32x2 loop whose reads come in batches of 4
-    // k-steps runs at 151-153 TFLOP/s with 2-3 waves per SIMD; with a read / wait / MFMA hand-over at every k-step, 136.
+    // Operand reads may be issued in GROUPS of KG k-steps, one group ahead of the MFMAs that consume them ([reads of group
+    // g+1][MFMAs of group g], one lgkmcnt wait per group).  Measured on the real layers (round 3, gpurun_out/r3c): KG = 4
+    // double-buffered and KG = 7 single-buffered are 3-5 % SLOWER than KG = 1 on the 7-tap layers (133 vs 138.5 TFLOP/s),
+    // KG = 2 equal, although a bare LDS-fed MFMA loop with batched reads reaches 151-153 TFLOP/s (tools/mfma_probe.hip): in
+    // the real loop the gap to that figure is the DMA issue (4 %), the per-chunk wait + barrier (1.3 %) and the epilogue
+    // (1.6 %), not the read schedule (timing builds with each piece removed, gpurun_out/r3d).
+    // The default therefore stays one k-step per group (operands of step s+1 fetched before the MFMAs of step s); the
+    // grouped forms remain selectable for A/B builds (kgroup_steps).
     constexpr int NS = C::KC / 2;                                       // k-steps per chunk
     constexpr int KG = kgroup_steps(NS, MT + NT);
     constexpr int NG = (NS + KG - 1) / KG;
@@ -545,7 +551,11 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 const float al = a.alpha_mid[row], inv = Ep[EP_MID * C::BM + row];
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
+#if defined(MVQ_EXP) && (MVQ_EXP & 16)
+                    Ht[row * C::BNP + (wn * NT + j) * 32 + l31] = acc[i][j][r] + bv + al * inv;
+#else
                     Ht[row * C::BNP + (wn * NT + j) * 32 + l31] = det_snake(acc[i][j][r] + bv, al, inv);
+#endif
                     acc[i][j][r] = 0.0f;
                 }
             }
@@ -560,8 +570,12 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         for (int g = 0; g < G; ++g)
 #pragma unroll
             for (int i = 0; i < MT; ++i) aw[0][g][i] = w2[(size_t)(2 * g) * a.Mpad + i * 32];
+#if defined(MVQ_EXP) && (MVQ_EXP & 32)
+        for (int grp = 0; grp < 1; ++grp) {
+#else
 #pragma unroll
         for (int grp = 0; grp < K2 / G; ++grp) {
+#endif
             if (grp + 1 < K2 / G) {
 #pragma unroll
                 for (int g = 0; g < G; ++g)
@@ -643,6 +657,11 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     constexpr int EHP = FUSE ? 1 : C::EH;            // epilogue passes
     constexpr int MTH = MT / EHP;                    // row groups per wave per pass
     constexpr int BMH = C::BM / EHP;
+    auto tile_row_of = [&](int lrow, int pass) __attribute__((always_inline)) {
+        if (EHP == 1) return lrow;
+        const int g = lrow >> 5;
+        return ((g / MTH) * MT + pass * MTH + (g % MTH)) * 32 + (lrow & 31);
+    };
 #pragma unroll
     for (int hp = 0; hp < EHP; ++hp) {
     __syncthreads();                                  // every wave is done with the staging buffers / the previous pass
@@ -654,19 +673,38 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
 #pragma unroll
             for (int j = 0; j < NT; ++j) Ct[row * C::BNP + (wn * NT + j) * 32 + l31] = acc[hp * MTH + il][j][r];
         }
+    // Skip-path prefetch: the residual quads this thread will add are requested NOW -- all of them at once, into the registers
+    // the accumulators just left -- so their HBM latency runs under the barrier and is paid once per pass, not once per group of
+    // four.  (Timing builds without the epilogue: the fused C = 64 unit 108 -> 120 TFLOP/s, C = 128 126 -> 135: most of that
+    // was exposed latency of these loads, not arithmetic.)
+    constexpr int NVQ = BMH * C::BN / 4;
+#ifdef MVQ_NO_RES_PREFETCH                              // A/B builds
+    constexpr bool PRE_RES = false;
+#else
+    constexpr bool PRE_RES = (UPS == 0) && (NVQ % C::NTHR == 0) && (NVQ / C::NTHR <= 16);
+#endif
+    constexpr int RES_IT = PRE_RES ? NVQ / C::NTHR : 1;
+    f32x4 res_q[RES_IT];
+    if (PRE_RES && has_res && a.ovec4) {
+#pragma unroll
+        for (int it = 0; it < RES_IT; ++it) {
+            const int e = tid + it * C::NTHR;
+            const int row = e / (C::BN / 4);
+            const int c4 = e - row * (C::BN / 4);
+            const int m = m0 + tile_row_of(row, hp), n = n0 + 4 * c4;
+            const bool ok = m < a.Mrows && n < a.Ncols;
+            const size_t off = ((size_t)b * a.Cout + (ok ? m : 0)) * a.Tout + (ok ? n : 0);
+            res_q[it] = *reinterpret_cast<const f32x4*>(a.residual + off);
+        }
+    }
     __syncthreads();
     // local row -> row of the block tile: group g = lrow / 32 belongs to wave row g / MTH, its (hp*MTH + g % MTH)-th group
-    auto tile_row = [&](int lrow) __attribute__((always_inline)) {
-        if (EHP == 1) return lrow;
-        const int g = lrow >> 5;
-        return ((g / MTH) * MT + hp * MTH + (g % MTH)) * 32 + (lrow & 31);
-    };
+    auto tile_row = [&](int lrow) __attribute__((always_inline)) { return tile_row_of(lrow, hp); };
 
     if (UPS == 0) {
         if (a.ovec4) {
             constexpr int NV = BMH * C::BN / 4;
-#pragma unroll 4
-            for (int e = tid; e < NV; e += C::NTHR) {
+            auto quad = [&](int e, int it) __attribute__((always_inline)) {
                 const int row = e / (C::BN / 4);
                 const int c4 = e - row * (C::BN / 4);
                 const int m = m0 + tile_row(row), n = n0 + 4 * c4;
@@ -682,7 +720,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                         v.z = v.z * det_dsnake(sv.z, ad, id); v.w = v.w * det_dsnake(sv.w, ad, id);
                     }
                     if (has_res) {
-                        const f32x4 rv = *reinterpret_cast<const f32x4*>(a.residual + off);
+                        const f32x4 rv = PRE_RES ? res_q[PRE_RES ? it : 0] : *reinterpret_cast<const f32x4*>(a.residual + off);
                         v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
                     }
                     const int nz = (a.tvalid && n + 4 > a.tvalid) ? n + 4 - a.tvalid : 0;     // trailing pad columns of this quad
@@ -702,6 +740,13 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     if (nz > 0) { v.w = 0.0f; if (nz > 1) v.z = 0.0f; if (nz > 2) v.y = 0.0f; if (nz > 3) v.x = 0.0f; }
                     *reinterpret_cast<f32x4*>(a.y + off) = v;
                 }
+            };
+            if (PRE_RES) {
+#pragma unroll
+                for (int it = 0; it < RES_IT; ++it) quad(tid + it * C::NTHR, it);
+            } else {
+#pragma unroll 4
+                for (int e = tid; e < NV; e += C::NTHR) quad(e, 0);
             }
         } else {
             constexpr int NE = BMH * C::BN;

@@ -95,34 +95,36 @@ __device__ __forceinline__ float det_gelu(float x)
     return (0.5f * x) * (1.0f + det_erf(x * 0.707106781186547524f));
 }
 
-// Snake needs sin(alpha*x)^2.  Working in TURNS removes the range reduction's Cody-Waite chain: t = x * (alpha/pi) is the phase
-// in half-periods, n = rint(t), f = t - n is EXACT in fp32 (|f| <= 0.5, both operands multiples of ulp(t)), and
-// sin(pi f)^2 = v*(c1 + c2 v + ... + c9 v^8), v = f^2 (Taylor in pi*f, truncation < 2e-9 at |f| = 0.5; measured 1.7e-7 abs
-// against libm over |t| <= 8).  14 VALU operations per Snake instead of 18 (round 2: mul, mul, rint, 3 fma of Cody-Waite, mul,
-// 8 fma, mul, fma) -- on this chip every VALU instruction is time the fp32 MFMAs do not get (tools/mfma_probe.hip).
-// The phase rounds twice (alpha/pi, then the product with x) where torch's sin(alpha*x) rounds once: the same order of error
-// (~1e-7 * |alpha x|) as the reference's own fp32 product, far inside every tolerance the fixtures are compared with.
-__device__ __forceinline__ float det_sin2_turns(float t)
+// Snake needs sin(alpha*x)^2.  Two things make it cheap (on this chip every VALU instruction is time the fp32 MFMAs do not
+// get: tools/mfma_probe.hip):
+//  * TURNS: t = x * (alpha/pi) is the phase in half-periods, n = rint(t), f = t - n is EXACT in fp32 (|f| <= 0.5, both
+//    operands multiples of ulp(t)) -- no Cody-Waite chain;
+//  * HALF ANGLE: w = sin(pi f / 2)^2 = u*(c1 + c2 u + ... + c5 u^4), u = f^2, needs 5 terms on |pi f / 2| <= pi/4, and
+//    sin(pi f)^2 = 4 w (1 - w); the truncation error of w is multiplied by 4(1 - 2w), which vanishes at the end of the range.
+// 11 operations per Snake (mul, rint, sub, mul, 4 fma, mul, fma, fma) instead of 18 in round 2; 1.1e-7 abs against libm over
+// |t| <= 8 (round 2: 1.7e-7).  The phase rounds twice (alpha/pi, then the product with x) where torch's sin(alpha*x) rounds
+// once: the same order of error (~1e-7 * |alpha x|) as the reference's own fp32 product, far inside every fixture tolerance.
+__device__ __forceinline__ float det_sin2q_turns(float t)        // sin(pi t)^2 / 4
 {
     const float n = __builtin_rintf(t);
     const float f = t - n;
-    const float v = f * f;
-    float p = dfma(v, 0.018191421404480934f, -0.14100298285484314f);
-    p = dfma(v, p, 0.8571953773498535f);
-    p = dfma(v, p, -3.951768159866333f);
-    p = dfma(v, p, 13.213128089904785f);
-    p = dfma(v, p, -30.1223201751709f);
-    p = dfma(v, p, 42.72840881347656f);
-    p = dfma(v, p, -32.469696044921875f);
-    p = dfma(v, p, 9.869604110717773f);
-    return v * p;
+    const float u = f * f;
+    float p = dfma(u, 0.012903445400297642f, -0.11766531318426132f);
+    p = dfma(u, p, 0.6676313877105713f);
+    p = dfma(u, p, -2.029356002807617f);
+    p = dfma(u, p, 2.4674010276794434f);
+    const float w = u * p;
+    return dfma(-w, w, w);                                        // w - w^2
 }
 
-// inv_alpha = 1.0f / (alpha + 1e-9f), precomputed once per channel (same IEEE division everywhere); alpha * (1/pi) is one
-// fp32 product per call site (hoisted out of the per-element loops by the compiler: alpha is per row)
+__device__ __forceinline__ float det_sin2_turns(float t) { return 4.0f * det_sin2q_turns(t); }
+
+// inv_alpha = 1.0f / (alpha + 1e-9f), precomputed once per channel (same IEEE division everywhere).  4 * inv_alpha is exact,
+// so fma(4 inv, q, x) == fma(inv, 4 q, x) = x + inv * sin^2; alpha * (1/pi) and 4 * inv_alpha are per-row values the compiler
+// hoists out of the per-element loops.
 __device__ __forceinline__ float det_snake(float x, float alpha, float inv_alpha)
 {
-    return dfma(inv_alpha, det_sin2_turns(x * (alpha * 0.318309886183790672f)), x);
+    return dfma(4.0f * inv_alpha, det_sin2q_turns(x * (alpha * 0.318309886183790672f)), x);
 }
 
 // sin(pi*t): n = rint(t), f = t - n exact, one odd polynomial f*(d0 + d1 v + ... + d7 v^7), sign from the parity of n

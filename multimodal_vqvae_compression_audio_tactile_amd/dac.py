@@ -117,11 +117,12 @@ class WNConv1d(_WNKeys, nn.Module):
 class WNConvTranspose1d(_WNKeys, nn.Module):
     """weight_norm(nn.ConvTranspose1d) parameter holder; weight_v is [Cin, Cout, k], norm over dim 0."""
 
-    def __init__(self, cin, cout, kernel_size, stride, padding):
+    def __init__(self, cin, cout, kernel_size, stride, padding, output_padding=0):
         super().__init__()
         if kernel_size != 2 * stride:
             raise MvqError("WNConvTranspose1d: the path covers kernel_size == 2*stride (every DAC DecoderBlock)")
         self.cin, self.cout, self.ks, self.stride, self.padding = cin, cout, kernel_size, stride, padding
+        self.output_padding = int(output_padding)
         v = torch.randn(cin, cout, kernel_size) / math.sqrt(cin * 2)
         self.weight_g = nn.Parameter(v.reshape(cin, -1).norm(dim=1).reshape(cin, 1, 1))
         self.weight_v = nn.Parameter(v)
@@ -146,7 +147,7 @@ class WNConvTranspose1d(_WNKeys, nn.Module):
     def run(self, x, alpha_in=None, alpha_out=None, alpha_dual=None, tout_rows=0, tvalid=0):
         return ops.conv_transpose1d(x, self.packed(), self.cout, self.stride, self.padding, bias=self.bias.detach(),
                                     alpha_in=alpha_in, alpha_out=alpha_out, alpha_dual=alpha_dual, tout_rows=tout_rows,
-                                    tvalid=tvalid)
+                                    tvalid=tvalid, output_padding=self.output_padding)
 
     def forward(self, x):
         return self.run(x)
@@ -240,10 +241,11 @@ class Encoder(nn.Module):
 
 
 class DecoderBlock(nn.Module):
-    def __init__(self, input_dim: int, output_dim: int, stride: int):
+    def __init__(self, input_dim: int, output_dim: int, stride: int, output_padding: bool = False):
         super().__init__()
         self.block = nn.Sequential(Snake1d(input_dim),
-                                   WNConvTranspose1d(input_dim, output_dim, 2 * stride, stride, math.ceil(stride / 2)),
+                                   WNConvTranspose1d(input_dim, output_dim, 2 * stride, stride, math.ceil(stride / 2),
+                                                     output_padding=(stride % 2) if output_padding else 0),
                                    ResidualUnit(output_dim, 1), ResidualUnit(output_dim, 3), ResidualUnit(output_dim, 9))
 
     def run(self, x, alpha_next=None, pre_snaked=False, t_in=None):
@@ -254,11 +256,11 @@ class DecoderBlock(nn.Module):
         a_in = None if pre_snaked else self.block[0].flat()
         rows, tv = 0, 0
         if t_in is not None:
-            s_, p_ = up.stride, up.padding
-            tn = (t_in - 1) * s_ - 2 * p_ + 2 * s_                       # true output length
-            tnat = (x.shape[-1] - 1) * s_ - 2 * p_ + 2 * s_              # what the (possibly padded) input rows would give
+            s_, p_, op_ = up.stride, up.padding, up.output_padding
+            tn = (t_in - 1) * s_ - 2 * p_ + 2 * s_ + op_                 # true output length
+            tnat = (x.shape[-1] - 1) * s_ - 2 * p_ + 2 * s_ + op_        # what the (possibly padded) input rows would give
             tp = (tn + 3) // 4 * 4
-            can_pad = tp != tn and tp <= tnat + p_ and up.cin % 32 == 0 and up.cout % 32 == 0
+            can_pad = tp != tn and tp <= tnat - op_ + p_ and up.cin % 32 == 0 and up.cout % 32 == 0
             rows = tp if can_pad else tn
             tv = tn if can_pad else 0
             rows = 0 if (rows == tnat and tv == 0) else rows
@@ -281,13 +283,17 @@ class DecoderBlock(nn.Module):
 class Decoder(nn.Module):
     """z[B,C,Tl] -> [B,1,~Tl*prod(rates)]  (83.4 GFLOP per segment)."""
 
-    def __init__(self, input_channel: int = 1024, channels: int = 1536, rates=DEC_RATES, d_out: int = 1):
+    def __init__(self, input_channel: int = 1024, channels: int = 1536, rates=DEC_RATES, d_out: int = 1,
+                 output_padding: bool = False):
+        """output_padding=True: every DecoderBlock's ConvTranspose1d gets ``output_padding = stride % 2`` (the variant believed
+        to be upstream's repository head: 75 tokens -> 24 000 samples).  Default = the 1.0.0 release (-> 23 992), which is what
+        every fixture in tests/golden assumes."""
         super().__init__()
         layers: List[nn.Module] = [WNConv1d(input_channel, channels, 7, padding=3)]
         out = channels
         for i, s in enumerate(rates):
             inp, out = channels // 2 ** i, channels // 2 ** (i + 1)
-            layers.append(DecoderBlock(inp, out, s))
+            layers.append(DecoderBlock(inp, out, s, output_padding))
         layers += [Snake1d(out), WNConv1d(out, d_out, 7, padding=3), nn.Tanh()]
         self.model = nn.Sequential(*layers)
 
@@ -437,7 +443,7 @@ class DAC(nn.Module):
 
     def __init__(self, encoder_dim=64, encoder_rates=ENC_RATES, latent_dim=None, decoder_dim=1536,
                  decoder_rates=DEC_RATES, n_codebooks=32, codebook_size=1024, codebook_dim=8, quantizer_dropout=0.0,
-                 sample_rate=24000):
+                 sample_rate=24000, decoder_output_padding=False):
         super().__init__()
         if latent_dim is None:
             latent_dim = encoder_dim * (2 ** len(encoder_rates))
@@ -445,7 +451,7 @@ class DAC(nn.Module):
         self.hop_length = int(math.prod(encoder_rates))
         self.encoder = Encoder(encoder_dim, encoder_rates, latent_dim)
         self.quantizer = ResidualVectorQuantize(latent_dim, n_codebooks, codebook_size, codebook_dim, float(quantizer_dropout))
-        self.decoder = Decoder(latent_dim, decoder_dim, decoder_rates)
+        self.decoder = Decoder(latent_dim, decoder_dim, decoder_rates, output_padding=bool(decoder_output_padding))
 
     @classmethod
     def load(cls, path, strict: bool = True, **kw):

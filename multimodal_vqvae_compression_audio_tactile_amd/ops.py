@@ -156,16 +156,18 @@ def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x
 
 
 def conv_transpose1d(x, wp, cout, stride, pad, bias=None, alpha_in=None, alpha_out=None, alpha_dual=None, tout_rows=0,
-                     tvalid=0):
-    """tout_rows / tvalid: zero-padded rows (include/mvq.h): row length of the output and its true length."""
+                     tvalid=0, output_padding=0):
+    """tout_rows / tvalid: zero-padded rows (include/mvq.h): row length of the output and its true length.
+    output_padding: torch's ConvTranspose1d argument (that many more samples at the end of each row)."""
     x = _dev(x, "x")
     B, cin, tin = x.shape
-    tout = int(tout_rows) if tout_rows else (tin - 1) * stride - 2 * pad + 2 * stride
+    tout = int(tout_rows) if tout_rows else (tin - 1) * stride - 2 * pad + 2 * stride + int(output_padding)
     out = torch.empty(B, cout, max(tout, 0), device=x.device, dtype=torch.float32)
     y2 = torch.empty_like(out) if alpha_dual is not None else None
-    check(_lib.lib().mvq_conv_transpose1d_padded_f32(x.data_ptr(), wp.data_ptr(), _p(bias), _p(alpha_in), _p(alpha_out),
-                                                     out.data_ptr(), _p(y2), _p(alpha_dual), B, cin, tin, cout, stride,
-                                                     pad, int(tout_rows), int(tvalid), _stream()), "mvq_conv_transpose1d_f32")
+    check(_lib.lib().mvq_conv_transpose1d_op_f32(x.data_ptr(), wp.data_ptr(), _p(bias), _p(alpha_in), _p(alpha_out),
+                                                 out.data_ptr(), _p(y2), _p(alpha_dual), B, cin, tin, cout, stride,
+                                                 pad, int(output_padding), int(tout_rows), int(tvalid), _stream()),
+          "mvq_conv_transpose1d_f32")
     return out if alpha_dual is None else (out, y2)
 
 

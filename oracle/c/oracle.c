@@ -162,11 +162,25 @@ int orc_conv_transpose1d_out_len(int Tin, int ks, int stride, int pad)
  *   y[co,to] = bias + sum_ci sum_{pos : kk = to + pad - pos*stride in [0,ks)} w[ci,co,kk] * xs[ci,pos]
  *   chain order: ci ascending, then pos ascending.
  * ---------------------------------------------------------------------------------------------- */
+void orc_conv_transpose1d_op(const float* x, const float* w, const float* bias, float* y,
+                             int B, int Cin, int Tin, int Cout, int ks, int stride, int pad, int output_padding,
+                             const float* alpha_in, const float* alpha_out);
+
 void orc_conv_transpose1d(const float* x, const float* w, const float* bias, float* y,
                           int B, int Cin, int Tin, int Cout, int ks, int stride, int pad,
                           const float* alpha_in, const float* alpha_out)
 {
-    int Tout = orc_conv_transpose1d_out_len(Tin, ks, stride, pad);
+    orc_conv_transpose1d_op(x, w, bias, y, B, Cin, Tin, Cout, ks, stride, pad, 0, alpha_in, alpha_out);
+}
+
+/* output_padding (torch.nn.ConvTranspose1d): `output_padding` more samples at the END of every row -- the same sum evaluated at
+ * those positions (only input positions that exist contribute).  The upstream DAC repository head is believed to pass
+ * output_padding = stride % 2 in its DecoderBlock (release 1.0.0, which the restatement follows by default, does not). */
+void orc_conv_transpose1d_op(const float* x, const float* w, const float* bias, float* y,
+                             int B, int Cin, int Tin, int Cout, int ks, int stride, int pad, int output_padding,
+                             const float* alpha_in, const float* alpha_out)
+{
+    int Tout = orc_conv_transpose1d_out_len(Tin, ks, stride, pad) + output_padding;
     if (Tout <= 0) return;
     float* xs = (float*)malloc((size_t)Cin * Tin * sizeof(float));
     for (int b = 0; b < B; ++b) {

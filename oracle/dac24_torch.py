@@ -93,11 +93,12 @@ class Encoder(nn.Module):
 
 
 class DecoderBlock(nn.Module):
-    def __init__(self, input_dim, output_dim, stride):
+    def __init__(self, input_dim, output_dim, stride, output_padding=False):
         super().__init__()
         self.block = nn.Sequential(Snake1d(input_dim),
                                    WNConvTranspose1d(input_dim, output_dim, kernel_size=2 * stride, stride=stride,
-                                                     padding=math.ceil(stride / 2)),
+                                                     padding=math.ceil(stride / 2),
+                                                     output_padding=(stride % 2) if output_padding else 0),
                                    ResidualUnit(output_dim, 1), ResidualUnit(output_dim, 3), ResidualUnit(output_dim, 9))
 
     def forward(self, x):
@@ -105,13 +106,13 @@ class DecoderBlock(nn.Module):
 
 
 class Decoder(nn.Module):
-    def __init__(self, input_channel=1024, channels=1536, rates=(8, 5, 4, 2), d_out=1):
+    def __init__(self, input_channel=1024, channels=1536, rates=(8, 5, 4, 2), d_out=1, output_padding=False):
         super().__init__()
         layers = [WNConv1d(input_channel, channels, kernel_size=7, padding=3)]
         out = channels
         for i, s in enumerate(rates):
             inp, out = channels // 2 ** i, channels // 2 ** (i + 1)
-            layers.append(DecoderBlock(inp, out, s))
+            layers.append(DecoderBlock(inp, out, s, output_padding))
         layers += [Snake1d(out), WNConv1d(out, d_out, kernel_size=7, padding=3), nn.Tanh()]
         self.model = nn.Sequential(*layers)
 

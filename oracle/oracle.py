@@ -97,19 +97,19 @@ def conv1d(x, w, bias=None, stride=1, dil=1, pad=0, alpha_in=None, residual=None
     return y
 
 
-def conv_transpose1d(x, w, bias=None, stride=1, pad=0, alpha_in=None, alpha_out=None):
+def conv_transpose1d(x, w, bias=None, stride=1, pad=0, alpha_in=None, alpha_out=None, output_padding=0):
     x_, xp = _f(x)
     w_, wp = _f(w)
     B, Cin, Tin = x_.shape
     Cin2, Cout, ks = w_.shape
-    assert Cin2 == Cin
-    Tout = (Tin - 1) * stride - 2 * pad + ks
+    assert Cin2 == Cin and 0 <= output_padding < max(stride, 1)
+    Tout = (Tin - 1) * stride - 2 * pad + ks + output_padding
     y = np.zeros((B, Cout, Tout), np.float32)
     b_, bp = _opt(bias)
     ai_, aip = _opt(None if alpha_in is None else np.reshape(alpha_in, -1))
     ao_, aop = _opt(None if alpha_out is None else np.reshape(alpha_out, -1))
-    lib().orc_conv_transpose1d(xp, wp, bp, y.ctypes.data_as(f32p), B, Cin, Tin, Cout, ks, stride, pad,
-                               aip, aop)
+    lib().orc_conv_transpose1d_op(xp, wp, bp, y.ctypes.data_as(f32p), B, Cin, Tin, Cout, ks, stride, pad, int(output_padding),
+                                  aip, aop)
     return y
 
 
@@ -253,8 +253,10 @@ def dac_encoder(sd, x, rates=ENC_RATES, prefix="", collect=None):
     return h
 
 
-def dac_decoder(sd, z, rates=DEC_RATES, prefix="", collect=None):
-    """Decoder.forward: conv k7 -> 4x DecoderBlock(snake, convT, 3 RU) -> snake -> conv k7 -> tanh."""
+def dac_decoder(sd, z, rates=DEC_RATES, prefix="", collect=None, output_padding=False):
+    """Decoder.forward: conv k7 -> 4x DecoderBlock(snake, convT, 3 RU) -> snake -> conv k7 -> tanh.
+    output_padding=True: the DecoderBlock variant with ``output_padding = stride % 2`` on its ConvTranspose1d (believed to be
+    upstream's repository head; the 1.0.0 release -- the default here -- has none): 75 tokens -> 24 000 samples, not 23 992."""
     P = prefix
     w, b = _wn(sd, P + "model.0")
     h = conv1d(z, w, b, pad=3)
@@ -262,7 +264,8 @@ def dac_decoder(sd, z, rates=DEC_RATES, prefix="", collect=None):
     for i, s in enumerate(rates):
         p = f"{P}model.{i + 1}"
         w, b = _wn(sd, p + ".block.1")          # ConvTranspose1d weight [Cin,Cout,k], WN over dim 0
-        h = conv_transpose1d(h, w, b, stride=s, pad=math.ceil(s / 2), alpha_in=sd[p + ".block.0.alpha"])
+        h = conv_transpose1d(h, w, b, stride=s, pad=math.ceil(s / 2), alpha_in=sd[p + ".block.0.alpha"],
+                             output_padding=(s % 2) if output_padding else 0)
         for j, dil in enumerate((1, 3, 9)):
             h = _residual_unit(sd, f"{p}.block.{j + 2}", h, dil)
         if collect is not None: collect.append((f"dec.b{i}", h))
