@@ -444,7 +444,9 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                                  : "=&s"(keep) : "v"(src[u]), "s"(dst) : "memory");
                 }
+#if !(defined(MVQ_EXP) && (MVQ_EXP & 64))               // timing build: pointers not advanced (same chunk re-read)
                 src[u] += step_b[u];
+#endif
             }
         };
         auto mfma_chunk_dma = [&](int stage, bool issue_next, int next_stage) __attribute__((always_inline)) {
