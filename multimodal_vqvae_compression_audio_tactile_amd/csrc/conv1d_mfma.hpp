@@ -893,7 +893,11 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
     // When the whole packed weight fits L2 comfortably (k = 1 convs), put the R row tiles of a column tile back to back
     // on one XCD instead: x is then read from HBM once instead of R times.
     a.row_fast = 0;
-    if (R > 1 && (size_t)a.Cin * KS * a.Mpad * sizeof(float) <= ((size_t)5 << 19)) {          // <= 2.5 MB
+    static const size_t row_fast_max = [] {                        // MVQ_ROWFAST_MAX_KB: A/B override of the 2.5 MB threshold
+        const char* e = getenv("MVQ_ROWFAST_MAX_KB");
+        return e ? (size_t)atol(e) * 1024 : ((size_t)5 << 19);
+    }();
+    if (R > 1 && (size_t)a.Cin * KS * a.Mpad * sizeof(float) <= row_fast_max) {               // <= 2.5 MB
         a.row_fast = (int)R;
         grid = dim3(((gx + 7) / 8) * 8 * R, 1);
     }

@@ -19,6 +19,7 @@ HIP-backed autograd Functions in train.py (same forward kernels, HIP backward ke
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -261,8 +262,13 @@ class _ProposedBase(nn.Module):
             return z_run, r_tokens, torch.cat(idx_all, dim=2) if idx_all else torch.zeros(0, B, Tlat, dtype=torch.int64)
         return z_run, r_tokens
 
-    TWO_STREAM_MAX_BATCH = 64     # up to this many segments the two encoder branches run on two HIP streams (measured:
-                                  # 8 % at B = 1-8, 5 % at 32, 1 % at 48-64, nothing from 128 on; tools/two_stream_probe.py)
+    # The two encoder branches (qa = A_QUANT(A_ENC(a)), zt = T_ENC(t)) are independent; up to this many segments they run on two
+    # HIP streams (round 1: 8 % at B = 1-8, 5 % at 32, 1 % at 48-64).  At 256 segments two streams still give 330.6 -> 329.7 ms
+    # per step (the under-filled tail / latent-rate launches of one branch overlap the other's; gpurun_out/r3l, twice on one
+    # box), but concurrent kernels stretch each other's durations, so the per-kernel HIP-event / rocprofv3 figures the bench
+    # reports (roofline of the dominant kernel) would no longer describe a kernel running alone.  The default therefore keeps
+    # one stream at throughput batch sizes; MVQ_TWO_STREAM_MAX_BATCH raises the cap.
+    TWO_STREAM_MAX_BATCH = int(os.environ.get("MVQ_TWO_STREAM_MAX_BATCH", "64"))
 
     def _encode_branches(self, a_1T, t_1T):
         """qa = A_QUANT(A_ENC(a)) and zt = T_ENC(t) are independent.  In the latency regime (few segments: every

@@ -75,6 +75,37 @@ def test_module_mirror_loads_reference_shaped_state_dicts():
     mvq.DAC(n_codebooks=4).load_state_dict(dac_sd, strict=True)
 
 
+def test_proposed_wrapper_mirrors_the_3_5_eval_script():
+    """Evaluation/compare_dacvsproposal_3.5_eval.py:374-411: ``ProposedWrapper(A_ENC, A_QUANT, T_ENC, T_DEC, c_lat)`` -- RVQ shape
+    from that script's module constants (10 books x K = 128, ...:68-69), ``forward_eval(a, t, books_use)`` with a required
+    ``books_use``; a checkpoint trained with 3 books (the script's comment at ...:68) loads strict=False as it does at ...:487."""
+    import inspect
+    import multimodal_vqvae_compression_audio_tactile_amd as mvq
+    from multimodal_vqvae_compression_audio_tactile_amd import proposed, synth
+    assert (proposed.RVQ_N_BOOKS_MAX, proposed.RVQ_EMBED, proposed.CODE_DIM, proposed.AR_CHUNK_TOK) == (10, 128, 96, 16)
+    assert list(inspect.signature(mvq.ProposedWrapper.__init__).parameters) == ["self", "A_ENC", "A_QUANT", "T_ENC", "T_DEC", "c_lat"]
+    fe = inspect.signature(mvq.ProposedWrapper.forward_eval).parameters
+    assert list(fe) == ["self", "a_1T", "t_1T", "books_use"] and fe["books_use"].default is inspect.Parameter.empty
+    da, dt = mvq.DAC(), mvq.DAC()
+    net = mvq.ProposedWrapper(da.encoder, da.quantizer, dt.encoder, dt.decoder, c_lat=1024)
+    assert len(net.vq.books) == 10 and tuple(net.vq.books[0].shape) == (128, 96)
+    assert not any(p.requires_grad for m in (net.A_ENC, net.A_QUANT, net.T_ENC, net.T_DEC) for p in m.parameters())
+    res = net.load_state_dict(synth.proposed_model_state(3, rvq_books=10, rvq_embed=128), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    res = net.load_state_dict(synth.proposed_model_state(3, rvq_books=3, rvq_embed=128), strict=False)     # "trained with 3"
+    assert sorted(res.missing_keys) == [f"vq.books.{i}" for i in range(3, 10)] and not res.unexpected_keys
+    ref = "/root/reference/Evaluation/compare_dacvsproposal_3.5_eval.py"
+    import os
+    if os.path.exists(ref):                                       # build container only: same key set as the reference's own class
+        from oracle import dac24_torch as T, ref_import
+        e35 = ref_import.eval35()
+        rd, rt = T.DAC(), T.DAC()
+        theirs = e35.ProposedWrapper(rd.encoder, rd.quantizer, rt.encoder, rt.decoder, c_lat=1024)
+        a = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        b = {k: tuple(v.shape) for k, v in theirs.state_dict().items()}
+        assert a == b
+
+
 def test_no_cpu_fallback():
     import multimodal_vqvae_compression_audio_tactile_amd as mvq
     from multimodal_vqvae_compression_audio_tactile_amd import ops

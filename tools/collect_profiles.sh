@@ -51,4 +51,8 @@ python3 -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 
     --force-collectives --no-cpu-baseline --steps 3 --warmup 2 > "$OUT/bench_train_1rank_rccl.json" 2> "$OUT/rccl_train.err" || exit 81
 python3 -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node 1 tools/corpus_eval.py --gpus 1 --clips 100 \
     --force-collectives > "$OUT/corpus_eval_1rank_rccl.json" 2> "$OUT/rccl_corpus.err" || exit 82
+echo "[9] multi-rank plumbing on one device: two-rank gloo rehearsal through the bare self-launch path, and the fatal RCCL path"
+MVQ_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --batch 32 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_2rank_one_device_rehearsal.json" 2> "$OUT/rehearsal.err" || exit 91
+MVQ_BENCH_ONE_DEVICE=1 MVQ_BENCH_REHEARSE_RCCL_FAILURE=1 timeout -k 10 120 python3 bench.py --gpus 2 --batch 8 --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/rccl_failure_rehearsal.out" 2> "$OUT/rccl_failure_rehearsal.err"
+echo "failure rehearsal exit code: $?" >> "$OUT/rccl_failure_rehearsal.err"
 echo done
