@@ -99,6 +99,94 @@ constexpr int kgroup_steps(int ns, int regs_per_step)
 #endif
 }
 
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+// ---- hand-placed operand reads of the LDS-DMA K loop (MVQ_ASM_READS = G k-steps per group; default 1; 0 = compiler-scheduled) ------
+// Left to itself the compiler feeds the MFMAs with ds_read2_b32 pairs, whose 8-bit offsets reach 255 dwords, so it re-bases the
+// LDS address with a v_add per k-step (16 per 56-MFMA chunk on the 7-tap tile) -- vector instructions the fp32 MFMAs pay for
+// (DESIGN.md section 6b).  This form issues every read as ds_read_b32 with a 16-bit immediate offset from three per-chunk base
+// addresses (1 VALU per chunk instead of 16), double-buffered: [reads of group g+1][s_waitcnt lgkmcnt(#reads of g+1)][MFMAs of
+// group g]; LDS reads return in order, so the counted wait is exact.  Measured (same box, 256-segment step): G = 1 331.5 -> 329.0
+// ms, every -m gpu test bit-exact; G = 2 / 4 are 1 % / 4 % SLOWER than the compiler's schedule (as its own grouped forms are).
+#ifndef MVQ_ASM_READS
+#define MVQ_ASM_READS 1
+#endif
+template <int OFF>
+__device__ __forceinline__ float lds_read_imm(unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read immediate offset is 16 bits");
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+    return v;
+}
+
+template <int KS, int STRIDE, int DIL, int BM, int XP, int MT, int NT, int NS, int G>
+struct AsmOperandLoop {
+    static constexpr int NG = (NS + G - 1) / G;
+    template <int S, int I>
+    static __device__ __forceinline__ void load_a(float (&av)[G][MT], unsigned a_addr)
+    {
+        if constexpr (I < MT) {
+            av[S % G][I] = lds_read_imm<(2 * S * BM + I * 32) * 4>(a_addr);
+            load_a<S, I + 1>(av, a_addr);
+        }
+    }
+    template <int S, int J>
+    static __device__ __forceinline__ void load_b(float (&bv)[G][NT], unsigned b_same, unsigned b_cross)
+    {
+        if constexpr (J < NT) {
+            constexpr int k0 = 2 * S;
+            constexpr int off0 = (k0 / KS) * XP + (k0 % KS) * DIL;
+            constexpr bool cross = ((k0 + 1) / KS) != (k0 / KS);
+            bv[S % G][J] = lds_read_imm<(off0 + J * 32 * STRIDE) * 4>(cross ? b_cross : b_same);
+            load_b<S, J + 1>(bv, b_same, b_cross);
+        }
+    }
+    template <int GI, int U>
+    static __device__ __forceinline__ void load_group(float (&av)[G][MT], float (&bv)[G][NT], unsigned a_addr, unsigned b_same, unsigned b_cross)
+    {
+        if constexpr (U < G && GI * G + U < NS) {
+            load_a<GI * G + U, 0>(av, a_addr);
+            load_b<GI * G + U, 0>(bv, b_same, b_cross);
+            load_group<GI, U + 1>(av, bv, a_addr, b_same, b_cross);
+        }
+    }
+    template <int GI>
+    static constexpr int group_reads() { return ((GI * G + G <= NS) ? G : (NS - GI * G > 0 ? NS - GI * G : 0)) * (MT + NT); }
+    template <int GI, int U>
+    static __device__ __forceinline__ void mfma_group(f32x16_t (&acc)[MT][NT], const float (&av)[G][MT], const float (&bv)[G][NT])
+    {
+        if constexpr (U < G && GI * G + U < NS) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[U][i], bv[U][j], acc[i][j], 0, 0, 0);
+            mfma_group<GI, U + 1>(acc, av, bv);
+        }
+    }
+    // groups GI, GI+1, ... ; buffers alternate (av0/bv0 for even groups)
+    template <int GI>
+    static __device__ __forceinline__ void run_from(f32x16_t (&acc)[MT][NT], float (&av0)[G][MT], float (&bv0)[G][NT], float (&av1)[G][MT],
+                                                    float (&bv1)[G][NT], unsigned a_addr, unsigned b_same, unsigned b_cross)
+    {
+        if constexpr (GI < NG) {
+            if constexpr (GI + 1 < NG) {
+                if constexpr ((GI + 1) % 2 == 0) load_group<GI + 1, 0>(av0, bv0, a_addr, b_same, b_cross);
+                else load_group<GI + 1, 0>(av1, bv1, a_addr, b_same, b_cross);
+            }
+            // LDS reads return in order: group GI has landed once at most the reads of group GI+1 are outstanding
+            constexpr int pending = (GI + 1 < NG) ? group_reads<GI + 1>() : 0;
+            asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(pending > 15 ? 15 : pending) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (GI % 2 == 0) mfma_group<GI, 0>(acc, av0, bv0);
+            else mfma_group<GI, 0>(acc, av1, bv1);
+            __builtin_amdgcn_sched_barrier(0);
+            run_from<GI + 1>(acc, av0, bv0, av1, bv1, a_addr, b_same, b_cross);
+        }
+    }
+};
+
 template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, int UPS>
 struct ConvCfg {
     static constexpr int BM = 32 * MT * WAVES_M;
@@ -449,7 +537,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
 #endif
             }
         };
-        auto mfma_chunk_dma = [&](int stage, bool issue_next, int next_stage) __attribute__((always_inline)) {
+        [[maybe_unused]] auto mfma_chunk_dma = [&](int stage, bool issue_next, int next_stage) __attribute__((always_inline)) {
             const float* wsrc = smem + stage * C::DMA_STAGE_FLOATS + a_base;
             const float* xs_same = smem + stage * C::DMA_STAGE_FLOATS + C::W_FLOATS + bd_same;
             const float* xs_cross = smem + stage * C::DMA_STAGE_FLOATS + C::W_FLOATS + bd_cross;
@@ -490,6 +578,21 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 __builtin_amdgcn_sched_group_barrier(0x008, MT * NT * KG, 0);
             }
         };
+#if MVQ_ASM_READS > 0
+        using AL = AsmOperandLoop<KS, STRIDE, DIL, C::BM, XP, MT, NT, NS, MVQ_ASM_READS>;
+        auto mfma_chunk_asm = [&](int stage, bool issue_next, int next_stage) __attribute__((always_inline)) {
+            const unsigned sb = lds0 + (unsigned)(stage * C::DMA_STAGE_FLOATS * 4);
+            const unsigned a_addr = sb + (unsigned)(a_base * 4);
+            const unsigned b_s = sb + (unsigned)((C::W_FLOATS + bd_same) * 4), b_c = sb + (unsigned)((C::W_FLOATS + bd_cross) * 4);
+            float av0[MVQ_ASM_READS][MT], bv0[MVQ_ASM_READS][NT], av1[MVQ_ASM_READS][MT], bv1[MVQ_ASM_READS][NT];
+            AL::template load_group<0, 0>(av0, bv0, a_addr, b_s, b_c);
+            if (issue_next) dma_chunk(next_stage);
+            AL::template run_from<0>(acc, av0, bv0, av1, bv1, a_addr, b_s, b_c);
+        };
+#define MVQ_CHUNK mfma_chunk_asm
+#else
+#define MVQ_CHUNK mfma_chunk_dma
+#endif
         dma_chunk(0);
         if (n_chunks > 1) dma_chunk(1);
         int st_c = 0, st_n2 = 2;                       // stage of chunk c / of chunk c+2
@@ -503,7 +606,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NU - 1) : "memory");
                 __syncthreads();
             }
-            mfma_chunk_dma(c & 1, (MVQ_EXP & 1) ? false : (c + 2 < n_chunks), 2);
+            MVQ_CHUNK(c & 1, (MVQ_EXP & 1) ? false : (c + 2 < n_chunks), 2);
         }
 #else
         for (int c = 0; c < n_chunks; ++c) {
@@ -512,7 +615,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             else if (n_issue == NU) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NU) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NU - 1) : "memory");
             __syncthreads();                          // ... in every wave; and stage (c+2)%3 is free (read during chunk c-1)
-            mfma_chunk_dma(st_c, c + 2 < n_chunks, st_n2);
+            MVQ_CHUNK(st_c, c + 2 < n_chunks, st_n2);
             st_c = st_c == 2 ? 0 : st_c + 1;
             st_n2 = st_n2 == 2 ? 0 : st_n2 + 1;
         }
