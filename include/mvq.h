@@ -343,7 +343,8 @@ int mvq_resample_f32(const float* x, const float* kern, float* y, int batch, int
 /* Ragged form (the resample step of psnr_3k_aligned_batch, ...5_eval.py:217-220, after a per-item alignment shift): item b
  * resamples x[b*pitch + off[b] : ... + len[b]]; off / len are DEVICE int32 arrays (they are computed from the device-side
  * shifts, so no host round trip sits between aligning and resampling).  y rows have pitch lout_pitch; samples at and past
- * ceil(newf*len[b]/orig) are written as zeros and that length goes to len_out[b] (may be NULL).  Same chains as above. */
+ * ceil(newf*len[b]/orig) are written as zeros and that length goes to len_out[b] (may be NULL).  Same chains as above.
+ * A slice is clamped to its row on the device (0 <= off, off + len <= pitch) and to lout_pitch output samples. */
 int mvq_resample_ragged_f32(const float* x, const float* kern, float* y, const int32_t* off, const int32_t* len, int32_t* len_out,
                             int batch, int pitch, int lout_pitch, int orig, int newf, int width, int ks, void* stream);
 

@@ -765,14 +765,19 @@ __global__ __launch_bounds__(256) void resample_ragged_kernel(const float* __res
     const float* kt = kern_in_lds ? ksm : kern;
     const int m = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
-    const int L = len[b];
-    const int Lo = (int)(((long long)newf * L + orig - 1) / orig);
+    // the slice is clamped to its row: a wrong offset / length on the device must not read outside x
+    int o = off[b];
+    o = o < 0 ? 0 : (o > pitch ? pitch : o);
+    int L = len[b];
+    L = L < 0 ? 0 : (L > pitch - o ? pitch - o : L);
+    int Lo = (int)(((long long)newf * L + orig - 1) / orig);
+    if (Lo > lout_pitch) Lo = lout_pitch;
     if (m == 0 && lout) lout[b] = Lo;
     if (m >= lout_pitch) return;
     float acc = 0.0f;
     if (m < Lo) {
         const int n = m / newf, p = m - n * newf;
-        const float* xb = x + (size_t)b * pitch + off[b];
+        const float* xb = x + (size_t)b * pitch + o;
         const float* kp = kt + (size_t)p * ks;
         const int j0 = n * orig - width;
         int k_lo = j0 < 0 ? -j0 : 0;
