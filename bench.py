@@ -434,7 +434,8 @@ def main():
                                 "flop_per_launch": d["flops"] / d["launches"],
                                 "share_of_conv_time": d["seconds"] / sum(v["seconds"] for v in summ.values())}
             conv_s = sum(v["seconds"] for v in summ.values()); conv_f = sum(v["flops"] for v in summ.values())
-            line["conv_stack"] = {"tflops": conv_f / conv_s * 1e-12, "seconds_per_step": conv_s / args.steps,
+            line["conv_stack"] = {"tflops": conv_f / conv_s * 1e-12, "frac_of_fp32_mfma_peak": conv_f / conv_s * 1e-12 / FP32_MFMA_PEAK_TFLOPS,
+                                  "seconds_per_step": conv_s / args.steps,
                                   "kernels": {k: {"tflops": v["flops"] / v["seconds"] * 1e-12,
                                                   "ms_per_step": 1e3 * v["seconds"] / args.steps,
                                                   "launches_per_step": v["launches"] // args.steps}
