@@ -333,6 +333,23 @@ int mvq_conv_transpose1d_op_f32(const float* x, const float* wp, const float* bi
                                 int batch, int cin, int tin, int cout, int stride, int pad, int output_padding, int tout_rows,
                                 int tvalid, void* stream);
 
+/* PACKED latent-rate rows (round 3).  At the latent rate a segment is 75 columns wide: one 96- or 128-column tile per segment
+ * leaves 22-41 % of the MFMAs on padding.  The decoder's first two layers therefore run on rows that hold `seg_per_row` segments
+ * at a period of `seg_period` columns (a multiple of 4), `seg_valid` of them data and the rest ZEROS -- the zero padding each
+ * conv would see between neighbours, so every data column is computed exactly as in the unpacked layer (same fma chains).
+ *   mvq_conv1d_packed_rows_f32: a stride-1 'same' conv (2*pad == (ks-1)*dil, pad <= seg_period - seg_valid) x[rows,cin,L] ->
+ *     y[rows,cout,L], L = seg_per_row * seg_period; gap columns of the output are written as zeros (also in y2).
+ *   mvq_conv_transpose1d_packed_rows_f32: ConvTranspose1d(kernel 2*stride, stride, pad) reading such rows and writing the
+ *     UNPACKED y[batch_out, cout, (seg_valid-1)*stride - 2*pad + 2*stride]: segment g of row r is batch item r*seg_per_row + g.
+ * Replaces nothing new in the reference: it is `T_DEC`'s `model.0` / `model.1.block.1` (Training/compare_dacvsproposal_5.py:322). */
+int mvq_conv1d_packed_rows_f32(const float* x, const float* wp, const float* bias, const float* residual, const float* alpha_out,
+                               float* y, float* y2, const float* alpha2, int rows, int cin, int cout, int ks, int dil, int pad,
+                               int act, int seg_per_row, int seg_period, int seg_valid, void* stream);
+int mvq_conv_transpose1d_packed_rows_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                                         const float* alpha_out, float* y, float* y2, const float* alpha2, int rows, int cin,
+                                         int cout, int stride, int pad, int seg_per_row, int seg_period, int seg_valid,
+                                         int batch_out, void* stream);
+
 /* Polyphase sinc resampler: torchaudio.transforms.Resample(orig, new) as the reference
  * calls it on every file (Training/compare_dacvsproposal_5.py:110-113, Evaluation/dac_vcpwq_proposed6_latency.py:151-156).
  * orig/newf are the rates divided by their gcd, kern[newf][ks] the filter bank (ks = 2*width + orig),

@@ -290,6 +290,64 @@ int mvq_conv1d_padded_f32(const float* x, const float* wp, const float* bias, co
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d");
 }
 
+static unsigned magic_div(int d) { return (unsigned)((((unsigned long long)1 << 32) + (unsigned)d - 1) / (unsigned)d); }   /* umulhi(n, magic) == n / d for n * d < 2^32 */
+
+int mvq_conv1d_packed_rows_f32(const float* x, const float* wp, const float* bias, const float* residual, const float* alpha_out,
+                               float* y, float* y2, const float* alpha2, int rows, int cin, int cout, int ks, int dil, int pad,
+                               int act, int seg_per_row, int seg_period, int seg_valid, void* stream)
+{
+    if (rows < 0 || cin <= 0 || cout <= 0 || ks <= 0 || dil <= 0 || pad < 0 || seg_per_row <= 0 || seg_period <= 0 || seg_valid < 0)
+        return fail(MVQ_EINVAL, "conv1d_packed_rows: bad shape");
+    if (seg_period % 4 != 0 || seg_valid > seg_period || (ks - 1) * dil != 2 * pad || pad > seg_period - seg_valid)
+        return fail(MVQ_EINVAL, "conv1d_packed_rows: needs a 'same' stride-1 conv, a period that is a multiple of 4 and a gap of at "
+                                "least `pad` zero columns between segments (period %d, valid %d, pad %d)", seg_period, seg_valid, pad);
+    if (act != MVQ_ACT_NONE && act != MVQ_ACT_TANH && act != MVQ_ACT_GELU) return fail(MVQ_EINVAL, "conv1d_packed_rows: bad act %d", act);
+    const long long t = (long long)seg_per_row * seg_period;
+    if (t * seg_period >= ((long long)1 << 32)) return fail(MVQ_EINVAL, "conv1d_packed_rows: row too long");
+    if (rows == 0 || seg_valid == 0) return MVQ_OK;
+    if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv1d_packed_rows: null tensor");
+    if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "conv1d_packed_rows: y2 and alpha2 go together");
+    mvq::ConvArgs a{};
+    a.x = x; a.wp = wp; a.bias = bias; a.residual = residual; a.alpha_out = alpha_out; a.y = y; a.y2 = y2; a.alpha2 = alpha2;
+    a.B = rows; a.Cin = cin; a.Tin = (int)t; a.Cout = cout; a.Tout = (int)t; a.pad = pad; a.Mpad = mvq::conv_mpad(cout);
+    a.Mrows = cout; a.Ncols = (int)t; a.act = act; a.up_s = 1;
+    a.tper = seg_period; a.tper_valid = seg_valid; a.tper_magic = magic_div(seg_period);
+    hipError_t e = dispatch_conv1d(a, ks, 1, dil, S(stream));
+    if (e == hipErrorInvalidValue) return fail(MVQ_EUNSUPPORTED, "conv1d_packed_rows: needs an MFMA-tiled shape");
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_packed_rows");
+}
+
+int mvq_conv_transpose1d_packed_rows_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
+                                         const float* alpha_out, float* y, float* y2, const float* alpha2, int rows, int cin,
+                                         int cout, int stride, int pad, int seg_per_row, int seg_period, int seg_valid,
+                                         int batch_out, void* stream)
+{
+    if (rows < 0 || cin <= 0 || cout <= 0 || stride <= 0 || pad < 0 || seg_per_row <= 0 || seg_period <= 0 || seg_valid <= 0 || batch_out < 0)
+        return fail(MVQ_EINVAL, "conv_transpose1d_packed_rows: bad shape");
+    /* a segment's outputs must not reach into its neighbour's: the first `pad` positions are dropped, and the last outputs come
+     * from input column seg_valid (a zero of the gap) -- which has to exist */
+    if (seg_valid >= seg_period || batch_out > rows * seg_per_row)
+        return fail(MVQ_EINVAL, "conv_transpose1d_packed_rows: needs at least one zero column between segments and rows * seg_per_row >= batch_out");
+    const long long tin = (long long)seg_per_row * seg_period;
+    const int tout = (seg_valid - 1) * stride - 2 * pad + 2 * stride;             /* per segment, as the unpacked layer gives */
+    const long long per_out = (long long)seg_period * stride;
+    if (tout <= 0 || tout > per_out) return fail(MVQ_EINVAL, "conv_transpose1d_packed_rows: bad segment length");
+    if (tin * stride * per_out >= ((long long)1 << 32)) return fail(MVQ_EINVAL, "conv_transpose1d_packed_rows: row too long");
+    if (rows == 0 || batch_out == 0) return MVQ_OK;
+    if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv_transpose1d_packed_rows: null tensor");
+    if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "conv_transpose1d_packed_rows: y2 and alpha2 go together");
+    const int mrows = cout * stride;
+    mvq::ConvArgs a{};
+    a.x = x; a.wp = wp; a.bias = bias; a.alpha_in = alpha_in; a.alpha_out = alpha_out; a.y = y; a.y2 = y2; a.alpha2 = alpha2;
+    a.B = rows; a.Cin = cin; a.Tin = (int)tin; a.Cout = cout; a.Tout = tout; a.pad = 1; a.Mpad = mvq::conv_mpad(mrows);
+    a.Mrows = mrows; a.Ncols = (int)tin;          /* no boundary column: column tin would only feed positions past the last segment */
+    a.up_s = stride; a.up_p = pad;
+    a.up_per_out = (int)per_out; a.up_valid_out = tout; a.up_seg = seg_per_row; a.up_btrue = batch_out; a.up_magic = magic_div((int)per_out);
+    hipError_t e = dispatch_convtr(a, S(stream));
+    if (e == hipErrorInvalidValue) return fail(MVQ_EUNSUPPORTED, "conv_transpose1d_packed_rows: needs an MFMA-tiled shape");
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv_transpose1d_packed_rows");
+}
+
 static bool ru_fusable(int c, int dil)
 {
     return (c == 64 || c == 96 || c == 128) && (dil == 1 || dil == 3 || dil == 9);

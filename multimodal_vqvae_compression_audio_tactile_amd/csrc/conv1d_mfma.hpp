@@ -80,6 +80,15 @@ struct ConvArgs {
     int tvalid;             // > 0: rows are zero-padded beyond their true length (a multiple-of-4 row length keeps every
                             // load / store 16-byte aligned): output columns >= tvalid are written as zeros, so the tail stays
                             // a valid zero padding for the next conv.  0: every column is data.
+    // PACKED latent-rate rows: a row holds `seg` segments at a period of `tper` columns, `tper_valid` of
+    // them data and the rest zeros (the conv's own zero padding between neighbours).  Stride-1 convs: output columns with
+    // (n mod tper) >= tper_valid are written as zeros.  Polyphase ConvTranspose1d reading such rows: output sample t of the
+    // packed row belongs to segment t / up_per_out at position t mod up_per_out, is kept only below up_valid_out, and goes to
+    // batch item b * up_seg + segment of the UNPACKED output y[up_btrue, Cout, Tout].  Magic numbers: q = umulhi(n, magic).
+    int tper, tper_valid;
+    unsigned tper_magic;
+    int up_per_out, up_valid_out, up_seg, up_btrue;
+    unsigned up_magic;
     char* name_out;         // host only: when set, launchers write the kernel instantiation name here and do not launch
     int name_len;
 };
@@ -620,6 +629,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             st_n2 = st_n2 == 2 ? 0 : st_n2 + 1;
         }
 #endif
+#undef MVQ_CHUNK
     } else {
     tile.load_chunk(0, wreg, xv, xs);
     __syncthreads();                                  // alpha table visible
@@ -745,13 +755,22 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 for (int j = 0; j < NT; ++j) {
                     const int n = n0 + (wn * NT + j) * 32 + l31;
                     int t = n * (UPS ? UPS : 1) + rr - a.up_p;
-                    const bool ok = mok && n < a.Ncols && t >= 0 && t < a.Tout;
+                    bool ok = mok && n < a.Ncols && t >= 0 && (a.up_per_out ? true : t < a.Tout);
                     t = ok ? t : 0;
+                    size_t ro = rowoff;
+                    if (a.up_per_out) {                               // packed input rows -> unpacked output
+                        const int sg = (int)__umulhi((unsigned)t, a.up_magic);
+                        t -= sg * a.up_per_out;
+                        const int bb = b * a.up_seg + sg;
+                        ok = ok && t < a.up_valid_out && bb < a.up_btrue;
+                        ro = ((size_t)(ok ? bb : 0) * a.Cout + co) * a.Tout;
+                        t = ok ? t : 0;
+                    }
                     float v = acc[i][j][r] + bv;
                     const bool tail = a.tvalid && t >= a.tvalid;
-                    if (ok && a.y2) a.y2[rowoff + t] = tail ? 0.0f : det_snake(v, a.alpha2[co], Ep[C::BM + lr]);
+                    if (ok && a.y2) a.y2[ro + t] = tail ? 0.0f : det_snake(v, a.alpha2[co], Ep[C::BM + lr]);
                     if (snake_out) v = det_snake(v, al, inv);
-                    if (ok) a.y[rowoff + t] = tail ? 0.0f : v;
+                    if (ok) a.y[ro + t] = tail ? 0.0f : v;
                 }
             }
         }
@@ -828,7 +847,11 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                         const f32x4 rv = PRE_RES ? res_q[PRE_RES ? it : 0] : *reinterpret_cast<const f32x4*>(a.residual + off);
                         v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
                     }
-                    const int nz = (a.tvalid && n + 4 > a.tvalid) ? n + 4 - a.tvalid : 0;     // trailing pad columns of this quad
+                    int nz = (a.tvalid && n + 4 > a.tvalid) ? n + 4 - a.tvalid : 0;           // trailing pad columns of this quad
+                    if (a.tper) {                                     // packed rows: the gap columns of every period (quads never straddle one)
+                        const int nn = n - (int)__umulhi((unsigned)n, a.tper_magic) * a.tper;
+                        nz = nn + 4 > a.tper_valid ? (nn >= a.tper_valid ? 4 : nn + 4 - a.tper_valid) : 0;
+                    }
                     if (a.y2) {
                         const float a2 = a.alpha2[m], i2 = Ep[C::BM + tile_row(row)];
                         f32x4 w = {det_snake(v.x, a2, i2), det_snake(v.y, a2, i2), det_snake(v.z, a2, i2), det_snake(v.w, a2, i2)};
@@ -866,7 +889,8 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     const int lr = tile_row(row);
                     if (a.dsn_src) v = v * det_dsnake(a.dsn_src[off], a.dsn_alpha[m], Ep[2 * C::BM + lr]);
                     if (has_res) v = v + a.residual[off];
-                    const bool tail = a.tvalid && n >= a.tvalid;
+                    bool tail = a.tvalid && n >= a.tvalid;
+                    if (a.tper) tail = n - (int)__umulhi((unsigned)n, a.tper_magic) * a.tper >= a.tper_valid;
                     if (a.y2) a.y2[off] = tail ? 0.0f : det_snake(v, a.alpha2[m], Ep[C::BM + lr]);
                     if (snake_out) v = det_snake(v, a.alpha_out[m], Ep[lr]);
                     if (do_tanh) v = det_tanh(v);
@@ -888,10 +912,18 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             const int tl = e - col * run;
             const int nl = tl / S, rr = tl - nl * S;
             const int co = (m0 + tile_row(col * S)) / S;
-            const int t = t_base + tl;
-            if (co < a.Cout && n0 + nl < a.Ncols && t >= 0 && t < a.Tout) {
+            int t = t_base + tl;
+            bool ok = co < a.Cout && n0 + nl < a.Ncols && t >= 0 && (a.up_per_out ? true : t < a.Tout);
+            int bb = b;
+            if (ok && a.up_per_out) {                                 // packed input rows -> unpacked output
+                const int sg = (int)__umulhi((unsigned)t, a.up_magic);
+                t -= sg * a.up_per_out;
+                bb = b * a.up_seg + sg;
+                ok = t < a.up_valid_out && bb < a.up_btrue;
+            }
+            if (ok) {
                 float v = Ct[(col * S + rr) * C::BNP + nl] + (ep_bias ? ep_bias[co] : 0.0f);
-                const size_t off = ((size_t)b * a.Cout + co) * a.Tout + t;
+                const size_t off = ((size_t)bb * a.Cout + co) * a.Tout + t;
                 const bool tail = a.tvalid && t >= a.tvalid;
                 const int lr = tile_row(col * S);                     // any phase row of this channel: same table entry
                 if (a.y2) a.y2[off] = tail ? 0.0f : det_snake(v, a.alpha2[co], Ep[C::BM + lr]);
@@ -1012,11 +1044,14 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
         // ConvTranspose1d, the extra boundary column do not count), every valid row, the whole K
         int last = a.n_base + a.n_tiles * C::BN;
         int lim = a.Ncols;
-        if (UPS > 0) lim = a.Ncols - 1;                               // Ncols = Tin + 1 GEMM columns for Tin input samples
+        if (UPS > 0 && !a.up_per_out) lim = a.Ncols - 1;              // Ncols = Tin + 1 GEMM columns for Tin input samples
         else if (a.tvalid > 0) lim = a.tvalid;
         if (last > lim) last = lim;
-        const int cols = last > a.n_base ? last - a.n_base : 0;
-        pi = prof_begin(nm, 2.0 * a.Cin * KS * a.Mrows * (double)cols * a.B, stream);
+        double cols = last > a.n_base ? last - a.n_base : 0;
+        // packed rows: only the data columns of every period count
+        if (a.tper) cols *= (double)a.tper_valid / a.tper;
+        if (a.up_per_out) cols *= (double)a.up_valid_out / a.up_per_out;
+        pi = prof_begin(nm, 2.0 * a.Cin * KS * a.Mrows * cols * a.B, stream);
     }
     hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), lds, stream, a);
     prof_end(pi, stream);

@@ -355,12 +355,63 @@ class Decoder(nn.Module):
         # next multiple of 4 so that every layer runs its 16-byte load / store paths (include/mvq.h "Zero-padded rows").
         t = z.shape[-1]
         tv = 0
+        if self._use_packed_latents(z):
+            return self._forward_fast_packed(z)
         if t % 4 and t > 0 and m[0].cin % 32 == 0:
             zp = torch.zeros(z.shape[0], z.shape[1], (t + 3) // 4 * 4, device=z.device, dtype=torch.float32)
             zp[..., :t] = z
             z, tv = zp, t
         h = m[0].run(z, alpha_out=m[1].block[0].flat(), tvalid=tv)
         for i in range(1, nblk + 1):
+            nxt = m[i + 1].block[0].flat() if i < nblk else m[nblk + 1].flat()
+            h, t = m[i].run(h, alpha_next=nxt, pre_snaked=True, t_in=t)
+        y = m[nblk + 2].run(h, tanh=True)
+        return y if y.shape[-1] == t else y[..., :t].contiguous()
+
+
+    # ---- packed latent-rate layers (include/mvq.h "PACKED latent-rate rows") ------------------------------
+    # Throughput batches only: model.0 (k7 conv) and the first block's ConvTranspose1d run on rows of PACK_SEG segments at a period
+    # of ceil((T + 3) / 4) * 4 columns (T = 75 -> 80: 8 x 80 = 640 = five full 128-column tiles, 94 % live columns instead of
+    # 78 %); the transposed conv writes the ordinary unpacked [B, C/2, 8T] tensor, everything behind it is unchanged.
+    # MVQ_PACKED_LATENTS=0 switches it off (A/B runs).
+    PACK_SEG = 8
+    PACK_MIN_BATCH = int(os.environ.get("MVQ_PACKED_MIN_BATCH", "32"))
+    PACKED = os.environ.get("MVQ_PACKED_LATENTS", "1") != "0"
+
+    def _use_packed_latents(self, z) -> bool:
+        m = self.model
+        up = m[1].block[1]
+        t = z.shape[-1]
+        return (self.PACKED and z.shape[0] >= self.PACK_MIN_BATCH and 0 < t <= 1024 and m[0].cin % 32 == 0 and m[0].cout % 128 == 0
+                and up.output_padding == 0 and up.cin % 32 == 0 and (up.cout * up.stride) % 128 == 0
+                and ((t - 1) * up.stride - 2 * up.padding + 2 * up.stride) % 4 == 0)
+
+    @torch.no_grad()
+    def _forward_fast_packed(self, z):
+        m = self.model
+        nblk = len(m) - 4
+        B, _, t = z.shape
+        per = (t + 3 + 3) // 4 * 4                      # >= 3 zero columns between segments: the k7 conv's padding
+        zp = ops.pack_segments(z, self.PACK_SEG, per)
+        c0, blk = m[0], m[1]
+        up, r0, r1, r2 = blk.block[1], blk.block[2], blk.block[3], blk.block[4]
+        hp = ops.conv1d_packed_rows(zp, c0.packed(), c0.cout, c0.ks, self.PACK_SEG, per, t, bias=c0.bias.detach(),
+                                    dil=c0.dilation, pad=c0.padding, alpha_out=blk.block[0].flat())
+        pre = r0.wants_presnaked()
+        out = ops.conv_transpose1d_packed_rows(hp, up.packed(), up.cout, up.stride, up.padding, self.PACK_SEG, per, t, B,
+                                               bias=up.bias.detach(), alpha_dual=r0.block[0].flat() if pre else None)
+        nxt = m[2].block[0].flat() if nblk > 1 else m[nblk + 1].flat()
+        if pre:
+            h, hs = out
+            h, hs = r0.run(h, x_snaked=hs, alpha_dual=r1.block[0].flat())
+            h, hs = r1.run(h, x_snaked=hs, alpha_dual=r2.block[0].flat())
+            h = r2.run(h, x_snaked=hs, alpha_next=nxt)
+        else:
+            h = r0.run(out)
+            h = r1.run(h)
+            h = r2.run(h, alpha_next=nxt)
+        t = h.shape[-1]
+        for i in range(2, nblk + 1):
             nxt = m[i + 1].block[0].flat() if i < nblk else m[nblk + 1].flat()
             h, t = m[i].run(h, alpha_next=nxt, pre_snaked=True, t_in=t)
         y = m[nblk + 2].run(h, tanh=True)

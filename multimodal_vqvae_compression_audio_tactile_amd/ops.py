@@ -171,6 +171,53 @@ def conv_transpose1d(x, wp, cout, stride, pad, bias=None, alpha_in=None, alpha_o
     return out if alpha_dual is None else (out, y2)
 
 
+def pack_segments(z, seg_per_row: int, seg_period: int):
+    """z[B, C, T] -> zeros[ceil(B / seg_per_row), C, seg_per_row * seg_period] with item b in columns
+    [(b % seg_per_row) * seg_period, ... + T) of row b // seg_per_row (the PACKED latent-rate layout, include/mvq.h)."""
+    B, C, T = z.shape
+    G = (B + seg_per_row - 1) // seg_per_row
+    zp = torch.zeros(G, C, seg_per_row, seg_period, device=z.device, dtype=torch.float32)
+    full = B // seg_per_row
+    if full:
+        zp[:full, :, :, :T] = z[:full * seg_per_row].reshape(full, seg_per_row, C, T).permute(0, 2, 1, 3)
+    if B > full * seg_per_row:
+        rest = B - full * seg_per_row
+        zp[full, :, :rest, :T] = z[full * seg_per_row:].permute(1, 0, 2)
+    return zp.reshape(G, C, seg_per_row * seg_period)
+
+
+def conv1d_packed_rows(xp, wp, cout, ks, seg_per_row, seg_period, seg_valid, bias=None, dil=1, pad=0, residual=None,
+                       alpha_out=None, alpha_dual=None, tanh=False):
+    """Stride-1 'same' conv on PACKED rows xp[G, cin, seg_per_row * seg_period]; the gap columns of the output are zeros."""
+    xp = _dev(xp, "xp")
+    G, cin, L = xp.shape
+    if L != seg_per_row * seg_period:
+        raise MvqError("conv1d_packed_rows: row length != seg_per_row * seg_period")
+    out = torch.empty(G, cout, L, device=xp.device, dtype=torch.float32)
+    y2 = torch.empty_like(out) if alpha_dual is not None else None
+    check(_lib.lib().mvq_conv1d_packed_rows_f32(xp.data_ptr(), wp.data_ptr(), _p(bias), _p(residual), _p(alpha_out), out.data_ptr(),
+                                                _p(y2), _p(alpha_dual), G, cin, cout, ks, dil, pad, 1 if tanh else 0,
+                                                seg_per_row, seg_period, seg_valid, _stream()), "mvq_conv1d_packed_rows_f32")
+    return out if alpha_dual is None else (out, y2)
+
+
+def conv_transpose1d_packed_rows(xp, wp, cout, stride, pad, seg_per_row, seg_period, seg_valid, batch_out, bias=None,
+                                 alpha_in=None, alpha_out=None, alpha_dual=None):
+    """ConvTranspose1d(kernel 2*stride, stride, pad) reading PACKED rows, writing the unpacked y[batch_out, cout, Tseg]."""
+    xp = _dev(xp, "xp")
+    G, cin, L = xp.shape
+    if L != seg_per_row * seg_period:
+        raise MvqError("conv_transpose1d_packed_rows: row length != seg_per_row * seg_period")
+    tout = (seg_valid - 1) * stride - 2 * pad + 2 * stride
+    out = torch.empty(batch_out, cout, max(tout, 0), device=xp.device, dtype=torch.float32)
+    y2 = torch.empty_like(out) if alpha_dual is not None else None
+    check(_lib.lib().mvq_conv_transpose1d_packed_rows_f32(xp.data_ptr(), wp.data_ptr(), _p(bias), _p(alpha_in), _p(alpha_out),
+                                                          out.data_ptr(), _p(y2), _p(alpha_dual), G, cin, cout, stride, pad,
+                                                          seg_per_row, seg_period, seg_valid, batch_out, _stream()),
+          "mvq_conv_transpose1d_packed_rows_f32")
+    return out if alpha_dual is None else (out, y2)
+
+
 def rvq_ema_forward(z, books, n_books_use=None, return_indices=False):
     """ResidualVQEMA.forward.  z[B,D,T]; books[nb,K,D] (stacked).  -> q[B,D,T] (, idx[nb_use, B*T] int64)."""
     z = _dev(z, "z"); books = _dev(books, "books")
