@@ -36,8 +36,20 @@ extern "C" {
 #define MVQ_ACT_TANH 1
 #define MVQ_ACT_GELU 2   /* exact-erf GELU (nn.GELU() of CrossPredictor.ffn); MFMA-tiled, non-transposed shapes only */
 
+/* ABI version.  2 (round 4): mvq_rvq_ema_step_f32 takes the larger 16-byte-aligned scratch that
+ * mvq_rvq_ema_step_scratch_bytes() reports (version 1 documented nb*B*T int32), mvq_profile_end2() reports truncation,
+ * mvq_build_flags() exists. */
 int mvq_abi_version(void);
 const char* mvq_last_error(void);
+/* How this library was built / is being driven: 0 for a product build with no A/B override in the environment.
+ *   0x1 MVQ_TIMING_BUILD, 0x2 MVQ_EXP (pieces of kernels compiled out: results are WRONG by construction), 0x4 MVQ_KGROUP /
+ *   MVQ_KPREFETCH, 0x8 MVQ_NO_RES_PREFETCH, 0x10 MVQ_ASM_READS > 1 -- compile-time switches of tools/conv_microbench.py's timing
+ *   builds (they do not compile without -DMVQ_TIMING_BUILD); 0x100 MVQ_NO_DMA, 0x200 MVQ_ROWFAST_MAX_KB, 0x400
+ *   MVQ_NO_TOKEN_RVQ -- environment overrides present (results stay correct, timings are not the product's);
+ *   0x10000 (informational, not refused) the compiler-scheduled operand loop MVQ_ASM_READS=0.
+ * The Python mirror refuses to load a library whose low 16 bits are non-zero unless MVQ_ALLOW_TIMING_BUILD=1;
+ * bench.py prints the value in its line. */
+unsigned mvq_build_flags(void);
 
 /* Per-launch HIP-event profiler (measurement aid of bench.py; no reference counterpart).  Between mvq_profile_begin() and
  * mvq_profile_end() every conv / residual-unit kernel launch of the library is bracketed by a HIP event pair recorded on
@@ -56,6 +68,8 @@ int mvq_profile_begin(void);
 /* writes at most max_entries rows; *n_entries = the number of rows WRITTEN (instantiations beyond the buffer are dropped).
  * Returns MVQ_EHIP when an event could not be created or recorded during the session (first such error; nothing is written). */
 int mvq_profile_end(mvq_profile_entry* out, int max_entries, int* n_entries);
+/* same, and *n_total = the number of instantiations the session recorded: *n_total > *n_entries means the table was truncated */
+int mvq_profile_end2(mvq_profile_entry* out, int max_entries, int* n_entries, int* n_total);
 /* creates the event pairs of n_launches launches ahead of time: call it before a timed region so that no hipEventCreate
  * falls inside it (events are pooled and reused across sessions). */
 int mvq_profile_reserve(int n_launches);

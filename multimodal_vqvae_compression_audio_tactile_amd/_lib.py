@@ -26,8 +26,10 @@ EXPORTS = {
     # name: (restype, argtypes)
     "mvq_profile_begin": (c_int, []),
     "mvq_profile_end": (c_int, [ctypes.POINTER(ProfileEntry), c_int, ctypes.POINTER(c_int)]),
+    "mvq_profile_end2": (c_int, [ctypes.POINTER(ProfileEntry), c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "mvq_profile_reserve": (c_int, [c_int]),
     "mvq_abi_version": (c_int, []),
+    "mvq_build_flags": (ctypes.c_uint, []),
     "mvq_last_error": (c_char_p, []),
     "mvq_device_query": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_char_p, c_int]),
     "mvq_weight_norm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -119,8 +121,19 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        # a timing build (pieces of kernels compiled out) or an A/B override in the environment must never pass for the product
+        flags = int(handle.mvq_build_flags())
+        if flags & 0xFFFF and _os.environ.get("MVQ_ALLOW_TIMING_BUILD") != "1":
+            raise MvqError(f"{SO_PATH}: mvq_build_flags() = {flags:#x} (timing build or MVQ_NO_DMA / MVQ_ROWFAST_MAX_KB / "
+                           "MVQ_NO_TOKEN_RVQ in the environment; include/mvq.h).  Only tools/conv_microbench.py-style A/B runs "
+                           "may load it: set MVQ_ALLOW_TIMING_BUILD=1 to do so.")
         _lib = handle
     return _lib
+
+
+def build_flags() -> int:
+    """mvq_build_flags() of the loaded library (0 = product build, no A/B override in the environment)."""
+    return int(lib().mvq_build_flags())
 
 
 def check(status: int, what: str) -> None:

@@ -30,6 +30,9 @@ hipEvent_t prof_event()
 }
 }  // namespace
 bool prof_enabled() { return g_prof_on; }
+// environment overrides a launcher has honoured (MVQ_NO_DMA, MVQ_ROWFAST_MAX_KB, MVQ_NO_TOKEN_RVQ): part of mvq_build_flags()
+static unsigned g_env_flags = 0;
+void note_env_override(unsigned bit) { __atomic_fetch_or(&g_env_flags, bit, __ATOMIC_RELAXED); }
 int prof_begin(const char* kernel_name, double flops, hipStream_t s)
 {
     if (!g_prof_on) return -1;
@@ -103,8 +106,15 @@ int mvq_profile_reserve(int n_launches)
 
 int mvq_profile_end(mvq_profile_entry* out, int max_entries, int* n_entries)
 {
-    /* *n_entries = rows WRITTEN (<= max_entries); kernels beyond max_entries are dropped, never written past the buffer */
+    return mvq_profile_end2(out, max_entries, n_entries, nullptr);
+}
+
+int mvq_profile_end2(mvq_profile_entry* out, int max_entries, int* n_entries, int* n_total)
+{
+    /* *n_entries = rows WRITTEN (<= max_entries); kernels beyond max_entries are dropped, never written past the buffer;
+     * *n_total = instantiations the session saw (> *n_entries means the buffer truncated the table) */
     mvq::g_prof_on = false;
+    if (n_total) *n_total = 0;
     if (!n_entries || max_entries < 0 || (max_entries > 0 && !out)) return fail(MVQ_EINVAL, "profile_end: bad argument");
     *n_entries = 0;
     auto recycle = [] {
@@ -141,10 +151,20 @@ int mvq_profile_end(mvq_profile_entry* out, int max_entries, int* n_entries)
         out[i++] = kv.second;
     }
     *n_entries = i;
+    if (n_total) *n_total = (int)agg.size();
     return MVQ_OK;
 }
 
-int mvq_abi_version(void) { return 1; }
+int mvq_abi_version(void) { return 2; }
+unsigned mvq_build_flags(void)
+{
+    /* every conv translation unit is compiled with the same flags (one Makefile rule); also peek at the environment knobs so
+     * that a process which has not launched anything yet already reports them */
+    if (getenv("MVQ_NO_DMA")) mvq::note_env_override(MVQ_BF_ENV_NO_DMA);
+    if (getenv("MVQ_ROWFAST_MAX_KB")) mvq::note_env_override(MVQ_BF_ENV_ROWFAST);
+    if (getenv("MVQ_NO_TOKEN_RVQ")) mvq::note_env_override(MVQ_BF_ENV_NO_TOKEN_RVQ);
+    return mvq::conv_compile_flags() | __atomic_load_n(&mvq::g_env_flags, __ATOMIC_RELAXED);
+}
 const char* mvq_last_error(void) { return g_err; }
 
 int mvq_device_query(int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len)

@@ -93,11 +93,58 @@ struct ConvArgs {
     int name_len;
 };
 
-// k-steps per operand-read group (see conv1d_mfma_body): 1 by default.  A/B builds: -DMVQ_KGROUP=n fixes the group size,
-// -DMVQ_KPREFETCH=0 selects the single-buffered form (reads of a group, wait, its MFMAs).
+// ---- timing-build fence ------------------------------------------------------------------------------------------------------
+// MVQ_EXP (pieces of a kernel compiled out: WRONG RESULTS by construction, only the clock is read), MVQ_KGROUP / MVQ_KPREFETCH
+// (operand-read grouping A/B), MVQ_NO_RES_PREFETCH and MVQ_ASM_READS > 1 exist for tools/conv_microbench.py's timing builds
+// only (MVQ_ASM_READS=0, the compiler-scheduled operand loop, is a correct fallback for a toolchain the ISA lint rejects: it
+// builds without the fence and shows up as an informational bit).  They compile only together with -DMVQ_TIMING_BUILD, and such a library reports itself through
+// mvq_build_flags() (include/mvq.h) -- _lib.lib() refuses to load it unless the caller opted in, bench.py prints the value.
 #ifndef MVQ_KPREFETCH
 #define MVQ_KPREFETCH 1
 #endif
+#ifndef MVQ_ASM_READS
+#define MVQ_ASM_READS 1
+#endif
+#if (defined(MVQ_EXP) || defined(MVQ_KGROUP) || defined(MVQ_NO_RES_PREFETCH) || MVQ_KPREFETCH != 1 || MVQ_ASM_READS > 1) && !defined(MVQ_TIMING_BUILD)
+#error "MVQ_EXP / MVQ_KGROUP / MVQ_KPREFETCH / MVQ_NO_RES_PREFETCH / MVQ_ASM_READS are timing-build switches: add -DMVQ_TIMING_BUILD (the library then reports mvq_build_flags() != 0)"
+#endif
+// bits of mvq_build_flags() that come from the compilation (api.hip adds the environment bits)
+#define MVQ_BF_TIMING_BUILD 0x1
+#define MVQ_BF_EXP 0x2
+#define MVQ_BF_KGROUP 0x4
+#define MVQ_BF_NO_RES_PREFETCH 0x8
+#define MVQ_BF_ASM_READS 0x10
+#define MVQ_BF_ASM_READS_OFF 0x10000     /* informational: compiler-scheduled operand loop (correct, slower) */
+#define MVQ_BF_ENV_NO_DMA 0x100
+#define MVQ_BF_ENV_ROWFAST 0x200
+#define MVQ_BF_ENV_NO_TOKEN_RVQ 0x400
+constexpr unsigned conv_compile_flags()
+{
+    unsigned f = 0;
+#ifdef MVQ_TIMING_BUILD
+    f |= MVQ_BF_TIMING_BUILD;
+#endif
+#ifdef MVQ_EXP
+    f |= MVQ_BF_EXP;
+#endif
+#if defined(MVQ_KGROUP) || MVQ_KPREFETCH != 1
+    f |= MVQ_BF_KGROUP;
+#endif
+#ifdef MVQ_NO_RES_PREFETCH
+    f |= MVQ_BF_NO_RES_PREFETCH;
+#endif
+#if MVQ_ASM_READS > 1
+    f |= MVQ_BF_ASM_READS;
+#elif MVQ_ASM_READS == 0
+    f |= MVQ_BF_ASM_READS_OFF;
+#endif
+    return f;
+}
+// environment overrides (A/B measurements) seen by a launcher: recorded once, reported by mvq_build_flags()
+void note_env_override(unsigned bit);
+
+// k-steps per operand-read group (see conv1d_mfma_body): 1 in a product build.  Timing builds: -DMVQ_KGROUP=n fixes the group
+// size, -DMVQ_KPREFETCH=0 selects the single-buffered form (reads of a group, wait, its MFMAs).
 constexpr int kgroup_steps(int ns, int regs_per_step)
 {
 #ifdef MVQ_KGROUP
@@ -110,16 +157,24 @@ constexpr int kgroup_steps(int ns, int regs_per_step)
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-// ---- hand-placed operand reads of the LDS-DMA K loop (MVQ_ASM_READS = G k-steps per group; default 1; 0 = compiler-scheduled) ------
+// ---- hand-placed operand reads of the LDS-DMA K loop (MVQ_ASM_READS = G k-steps per group; 1 in a product build; 0 = compiler-scheduled) ------
 // Left to itself the compiler feeds the MFMAs with ds_read2_b32 pairs, whose 8-bit offsets reach 255 dwords, so it re-bases the
 // LDS address with a v_add per k-step (16 per 56-MFMA chunk on the 7-tap tile) -- vector instructions the fp32 MFMAs pay for
 // (DESIGN.md section 6b).  This form issues every read as ds_read_b32 with a 16-bit immediate offset from three per-chunk base
 // addresses (1 VALU per chunk instead of 16), double-buffered: [reads of group g+1][s_waitcnt lgkmcnt(#reads of g+1)][MFMAs of
-// group g]; LDS reads return in order, so the counted wait is exact.  Measured (same box, 256-segment step): G = 1 331.5 -> 329.0
-// ms, every -m gpu test bit-exact; G = 2 / 4 are 1 % / 4 % SLOWER than the compiler's schedule (as its own grouped forms are).
-#ifndef MVQ_ASM_READS
-#define MVQ_ASM_READS 1
-#endif
+// group g].  Measured (same box, 256-segment step): G = 1 331.5 -> 329.0 ms, every -m gpu test bit-exact; G = 2 / 4 are 1 % / 4 %
+// SLOWER than the compiler's schedule (as its own grouped forms are).
+//
+// What makes the counted wait sound, and what keeps the compiler out of it:
+//  * LDS reads of one wave return in order, and a counted lgkmcnt(N) only ever waits LONGER when something else (a scalar load)
+//    is outstanding too: with the N reads of group g+1 behind them, "at most N outstanding" implies every read of group g is done.
+//  * LLVM's waitcnt pass does not see loads issued from inline asm, so the registers a ds_read asm defines are IN FLIGHT until the
+//    wait.  The wait asm therefore takes the group's registers as "+v" operands: every MFMA consumes the value the WAIT defines,
+//    not the one the read defines, so no pass can move a consumer above the wait, and between a read and its wait nothing but
+//    further reads / the DMA issue is emitted (sched_barrier on both sides).  What this cannot exclude is a register copy or
+//    spill of an in-flight register inserted by the allocator; tools/isa_lint.py (run by tests/test_isa_lint.py, CPU suite)
+//    disassembles the shipped code object and fails if ANY instruction touches a ds_read destination before the s_waitcnt that
+//    covers it, if a DMA-ring kernel uses scratch, or if an M0 write is not followed by s_nop + global_load_lds + restore.
 template <int OFF>
 __device__ __forceinline__ float lds_read_imm(unsigned addr)
 {
@@ -127,6 +182,37 @@ __device__ __forceinline__ float lds_read_imm(unsigned addr)
     float v;
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
     return v;
+}
+// s_waitcnt lgkmcnt(P) that DEFINES the registers it makes valid (tied "+v" operands)
+template <int P> __device__ __forceinline__ void lgkm_wait_tie(float& a, float& b)
+{ asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(P) : "memory"); }
+template <int P> __device__ __forceinline__ void lgkm_wait_tie(float& a, float& b, float& c)
+{ asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(P) : "memory"); }
+template <int P> __device__ __forceinline__ void lgkm_wait_tie(float& a, float& b, float& c, float& d)
+{ asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(P) : "memory"); }
+template <int P> __device__ __forceinline__ void lgkm_wait_tie(float& a, float& b, float& c, float& d, float& e)
+{ asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(P) : "memory"); }
+template <int P> __device__ __forceinline__ void lgkm_wait_tie(float& a, float& b, float& c, float& d, float& e, float& f)
+{ asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(P) : "memory"); }
+// one k-step's operands (MT + NT registers, 2..6)
+template <int P, int MT, int NT>
+__device__ __forceinline__ void lgkm_wait_step(float (&av)[MT], float (&bv)[NT])
+{
+    static_assert(MT >= 1 && NT >= 1 && MT + NT <= 6, "operand registers per k-step");
+    if constexpr (MT == 1 && NT == 1) lgkm_wait_tie<P>(av[0], bv[0]);
+    else if constexpr (MT == 2 && NT == 1) lgkm_wait_tie<P>(av[0], av[1], bv[0]);
+    else if constexpr (MT == 1 && NT == 2) lgkm_wait_tie<P>(av[0], bv[0], bv[1]);
+    else if constexpr (MT == 2 && NT == 2) lgkm_wait_tie<P>(av[0], av[1], bv[0], bv[1]);
+    else if constexpr (MT == 3 && NT == 1) lgkm_wait_tie<P>(av[0], av[1], av[2], bv[0]);
+    else if constexpr (MT == 1 && NT == 3) lgkm_wait_tie<P>(av[0], bv[0], bv[1], bv[2]);
+    else if constexpr (MT == 4 && NT == 1) lgkm_wait_tie<P>(av[0], av[1], av[2], av[3], bv[0]);
+    else if constexpr (MT == 1 && NT == 4) lgkm_wait_tie<P>(av[0], bv[0], bv[1], bv[2], bv[3]);
+    else if constexpr (MT == 3 && NT == 2) lgkm_wait_tie<P>(av[0], av[1], av[2], bv[0], bv[1]);
+    else if constexpr (MT == 2 && NT == 3) lgkm_wait_tie<P>(av[0], av[1], bv[0], bv[1], bv[2]);
+    else if constexpr (MT == 4 && NT == 2) lgkm_wait_tie<P>(av[0], av[1], av[2], av[3], bv[0], bv[1]);
+    else if constexpr (MT == 2 && NT == 4) lgkm_wait_tie<P>(av[0], av[1], bv[0], bv[1], bv[2], bv[3]);
+    else if constexpr (MT == 3 && NT == 3) lgkm_wait_tie<P>(av[0], av[1], av[2], bv[0], bv[1], bv[2]);
+    else static_assert(MT + NT <= 5 || MT == 4 || NT == 4 || (MT == 3 && NT == 3), "unsupported operand shape");
 }
 
 template <int KS, int STRIDE, int DIL, int BM, int XP, int MT, int NT, int NS, int G>
@@ -174,6 +260,22 @@ struct AsmOperandLoop {
             mfma_group<GI, U + 1>(acc, av, bv);
         }
     }
+    // the counted wait of group GI: the first k-step's registers ride through the s_waitcnt itself, the others (G > 1, timing
+    // builds) through empty asm statements behind it (volatile asm statements keep their order)
+    template <int GI, int PW, int U>
+    static __device__ __forceinline__ void wait_group(float (&av)[G][MT], float (&bv)[G][NT])
+    {
+        if constexpr (U < G && GI * G + U < NS) {
+            if constexpr (U == 0) lgkm_wait_step<PW, MT, NT>(av[0], bv[0]);
+            else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(av[U][i]));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(bv[U][j]));
+            }
+            wait_group<GI, PW, U + 1>(av, bv);
+        }
+    }
     // groups GI, GI+1, ... ; buffers alternate (av0/bv0 for even groups)
     template <int GI>
     static __device__ __forceinline__ void run_from(f32x16_t (&acc)[MT][NT], float (&av0)[G][MT], float (&bv0)[G][NT], float (&av1)[G][MT],
@@ -184,9 +286,13 @@ struct AsmOperandLoop {
                 if constexpr ((GI + 1) % 2 == 0) load_group<GI + 1, 0>(av0, bv0, a_addr, b_same, b_cross);
                 else load_group<GI + 1, 0>(av1, bv1, a_addr, b_same, b_cross);
             }
-            // LDS reads return in order: group GI has landed once at most the reads of group GI+1 are outstanding
+            // LDS reads return in order: group GI has landed once at most the reads of group GI+1 are outstanding.  The wait
+            // re-defines group GI's registers (tied operands): their consumers depend on the wait, not on the reads.
             constexpr int pending = (GI + 1 < NG) ? group_reads<GI + 1>() : 0;
-            asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(pending > 15 ? 15 : pending) : "memory");
+            constexpr int PW = pending > 15 ? 15 : pending;
+            __builtin_amdgcn_sched_barrier(0);         // nothing (no scalar load, no VALU) between the reads and their wait
+            if constexpr (GI % 2 == 0) wait_group<GI, PW, 0>(av0, bv0);
+            else wait_group<GI, PW, 0>(av1, bv1);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (GI % 2 == 0) mfma_group<GI, 0>(acc, av0, bv0);
             else mfma_group<GI, 0>(acc, av1, bv1);
@@ -491,7 +597,13 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         }
     };
 
-    if (VEC && a.dma) {
+    // the LDS-DMA form exists only in instantiations whose 3-stage ring the launcher can ever select (launch_conv1d_mfma /
+    // launch_residual_unit set a.dma under the same size conditions): the others do not carry its code or its registers
+    constexpr bool DMA_FITS = FUSE ? ((size_t)C::LDS_FLOATS_FUSE_DMA + 3 * C::BM) * 4 * 2 <= 160 * 1024 : (size_t)C::LDS_FLOATS_DMA * 4 <= 64 * 1024;
+    bool use_dma = false;
+    if constexpr (VEC && DMA_FITS) use_dma = a.dma != 0;
+    if (use_dma) {
+      if constexpr (VEC && DMA_FITS) {
         // ---- K loop with global -> LDS DMA staging (global_load_lds_dwordx4: 16 bytes per lane, 1 KiB per wave-instruction,
         // no register round trip, no ds_write) into a ring of THREE stages: while chunk c is multiplied out of stage c % 3 the
         // DMA of chunk c+2 is in flight into stage (c+2) % 3, which was last read during chunk c-1, i.e. before the barrier
@@ -630,6 +742,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         }
 #endif
 #undef MVQ_CHUNK
+      }
     } else {
     tile.load_chunk(0, wreg, xv, xs);
     __syncthreads();                                  // alpha table visible
@@ -971,7 +1084,7 @@ inline hipError_t launch_residual_unit(const ConvArgs& a_in, hipStream_t stream)
     a.ovec4 = (a.Tout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
               ((reinterpret_cast<uintptr_t>(a.residual) & 15) == 0);
     // input already carries its Snake (the producer's dual output) and rows are 16-byte: the 7-tap stage runs on the LDS-DMA ring
-    a.dma = (conv_dma_rows_ok(a) && ((size_t)C::LDS_FLOATS_FUSE_DMA + 3 * C::BM) * 4 * 2 <= 160 * 1024) ? 1 : 0;
+    a.dma = (conv_dma_rows_ok(a) && ((size_t)C::LDS_FLOATS_FUSE_DMA + 3 * C::BM) * 4 * 2 <= 160 * 1024) ? 1 : 0;   // == DMA_FITS of the body
     const size_t lds = a.dma ? (size_t)C::LDS_FLOATS_FUSE_DMA * 4 + (size_t)3 * C::BM * 4
                              : (size_t)C::LDS_FLOATS_FUSE * 4 + (size_t)3 * C::BM * 4 + (size_t)2 * a.Cin * 4;
     auto kern = residual_unit_kernel<DIL, CK, MT, NT, WAVES_M, WAVES_N>;
@@ -1030,6 +1143,7 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
     a.row_fast = 0;
     static const size_t row_fast_max = [] {                        // MVQ_ROWFAST_MAX_KB: A/B override of the 2.5 MB threshold
         const char* e = getenv("MVQ_ROWFAST_MAX_KB");
+        if (e) note_env_override(MVQ_BF_ENV_ROWFAST);
         return e ? (size_t)atol(e) * 1024 : ((size_t)5 << 19);
     }();
     if (R > 1 && (size_t)a.Cin * KS * a.Mpad * sizeof(float) <= row_fast_max) {               // <= 2.5 MB
@@ -1063,7 +1177,7 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
 // MVQ_NO_DMA=1 in the environment switches it off (A/B measurements).
 inline bool conv_dma_rows_ok(const ConvArgs& a)
 {
-    static const bool off = getenv("MVQ_NO_DMA") != nullptr;
+    static const bool off = [] { const bool o = getenv("MVQ_NO_DMA") != nullptr; if (o) note_env_override(MVQ_BF_ENV_NO_DMA); return o; }();
     return !off && !a.alpha_in && a.Tin % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
 }
 

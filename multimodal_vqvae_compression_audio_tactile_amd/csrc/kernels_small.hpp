@@ -24,6 +24,7 @@ struct BigLdsOptIn {
     }
 };
 
+void note_env_override(unsigned bit);                                      // api.hip: environment A/B knobs seen -> mvq_build_flags()
 int prof_begin(const char* kernel_name, double flops, hipStream_t s);     // api.hip (see conv1d_mfma.hpp)
 void prof_end(int idx, hipStream_t s);
 bool prof_enabled();

@@ -453,7 +453,11 @@ hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_o
     const int N = B * T;
     if (N == 0) return hipSuccess;
     // a handful of tokens (latency regime): one block per token, nothing staged
-    static const bool no_token_form = getenv("MVQ_NO_TOKEN_RVQ") != nullptr;      // A/B measurements
+    static const bool no_token_form = [] {                                          // A/B measurements; reported by mvq_build_flags()
+        const bool o = getenv("MVQ_NO_TOKEN_RVQ") != nullptr;
+        if (o) mvq::note_env_override(0x400 /* MVQ_BF_ENV_NO_TOKEN_RVQ */);
+        return o;
+    }();
     if (N <= 256 && D % 4 == 0 && D <= 128 && !no_token_form) {
         hipLaunchKernelGGL(rvq_ema_forward_token_kernel, dim3(N), dim3(256), 0, s, z, books, q_out, idx_out, B, D, T, nb, K, update_residual);
         return hipGetLastError();

@@ -111,11 +111,14 @@ def profile_reserve(n_launches: int) -> None:
 def profile_end() -> dict:
     """Stop and collect: {kernel instantiation name: {"seconds", "flops", "launches"}} (synchronises)."""
     import ctypes
-    buf = (_lib.ProfileEntry * 256)()
-    n = ctypes.c_int(0)
-    check(_lib.lib().mvq_profile_end(buf, 256, ctypes.byref(n)), "mvq_profile_end")
+    cap = 1024
+    buf = (_lib.ProfileEntry * cap)()
+    n, total = ctypes.c_int(0), ctypes.c_int(0)
+    check(_lib.lib().mvq_profile_end2(buf, cap, ctypes.byref(n), ctypes.byref(total)), "mvq_profile_end2")
+    if total.value > n.value:        # never hand a truncated table to the roofline arithmetic
+        raise MvqError(f"mvq_profile_end2: {total.value} kernel instantiations recorded, buffer holds {cap}")
     return {buf[i].kernel.decode(): {"seconds": buf[i].seconds, "flops": buf[i].flops, "launches": buf[i].launches}
-            for i in range(min(n.value, 256))}
+            for i in range(n.value)}
 
 
 def residual_unit_kernel_name(c, dil) -> str:

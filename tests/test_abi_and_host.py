@@ -24,7 +24,8 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(so, n)]
     assert not missing, missing
     assert sorted(_lib.EXPORTS) == names, set(names) ^ set(_lib.EXPORTS)     # the ctypes table binds all of them
-    assert _lib.lib().mvq_abi_version() == 1
+    assert _lib.lib().mvq_abi_version() == 2
+    assert _lib.lib().mvq_build_flags() == 0 == _lib.build_flags()          # product build, no A/B knob in the environment
 
 
 def test_host_only_entry_points():

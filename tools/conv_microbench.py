@@ -1,5 +1,11 @@
 #!/usr/bin/env python3
-"""Per-layer timing of every conv shape on the path (HIP events, one GPU).  usage: conv_microbench.py [B] [filter]"""
+"""Per-layer timing of every conv shape on the path (HIP events, one GPU).  usage: conv_microbench.py [B] [filter]
+
+A/B against another build of the SAME sources: MVQ_LIB_PATH=/path/to/libmvq_other.so.  Timing builds (pieces of a kernel
+compiled out -- wrong results by construction, only the clock is read) are made with
+    make -C multimodal_vqvae_compression_audio_tactile_amd/csrc OBJDIR=build_exp OUT=../libmvq_exp.so EXTRA="-DMVQ_TIMING_BUILD -DMVQ_EXP=4"
+and load only with MVQ_ALLOW_TIMING_BUILD=1 in the environment (mvq_build_flags() != 0; include/mvq.h); the same variable is
+needed when an A/B knob (MVQ_NO_DMA, MVQ_ROWFAST_MAX_KB, MVQ_NO_TOKEN_RVQ) is set."""
 import math, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
