@@ -297,11 +297,20 @@ def main():
         opt = (torch.optim.AdamW if args.torch_optim else mvq.optim.AdamW)(params, lr=2e-4, weight_decay=1e-5)   # ...5.py:54-55,367
 
     phase_ev = []                # train: per step, (name, start event, end event) on the current stream = the stream of every launch
+    # the phase events of the timed region exist BEFORE it starts (torch creates the hipEvent at the first record(), so each one
+    # is recorded once here): no hipEventCreate inside the timed loop, like the library's own per-launch events
+    phase_pool = []
+    if train:
+        for _ in range(2 * 3 * args.steps):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            phase_pool.append(e)
 
     def phase(name, fn):
         if not train or not collect_phases:
             return fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0 = phase_pool.pop() if phase_pool else torch.cuda.Event(enable_timing=True)
+        e1 = phase_pool.pop() if phase_pool else torch.cuda.Event(enable_timing=True)
         e0.record(); r = fn(); e1.record()
         phase_ev.append((name, e0, e1))
         return r
@@ -364,6 +373,7 @@ def main():
     unprof_ms = None
     if kev and args.steps > 0:
         n_un = min(args.steps, 3)
+        barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(n_un):
@@ -371,12 +381,34 @@ def main():
         torch.cuda.synchronize()
         unprof_ms = 1e3 * (time.perf_counter() - t1) / n_un
 
+    # Parity spot check of the HEADLINE configuration (inference workloads): sampled segments of this batch, re-run one at a
+    # time (B = 1: other tiles, other launch plan, same fma chains), must equal their rows of the B-segment output bit for bit.
+    # A mismatch fails the run: a throughput number for wrong results is not reported.
+    spot = None
+    if not train:
+        idx = sorted({0, B // 3, B - 1})
+        bad = []
+        for i in idx:
+            yi = (net.forward_eval_tactile_only(t[i:i + 1], books_use=None) if tact
+                  else net.forward_eval(a[i:i + 1], t[i:i + 1], books_use=None))
+            if yi.shape[1:] != y.shape[1:] or not torch.equal(yi[0], y[i]):
+                bad.append(i)
+        torch.cuda.synchronize()
+        spot = {"segments": idx, "bit_equal_to_B1": not bad, "mismatching": bad}
+        if bad:
+            print(f"[bench rank {rank}] parity spot check FAILED: segments {bad} of the B={B} output differ from their B=1 runs", file=sys.stderr, flush=True)
+
     if dist:
         tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=grp)              # grp is None (default gloo group) in the rehearsal
         elapsed = float(tt.item())
 
     out_ok = bool(torch.isfinite(y).all().item()) and y.shape[0] == B
+    spot_ok = spot is None or spot["bit_equal_to_B1"]
+    if dist:                                                   # a failing rank fails the job
+        so = torch.tensor([1.0 if spot_ok else 0.0], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(so, op=dist.ReduceOp.MIN, group=grp)
+        spot_ok = bool(so.item() == 1.0)
 
     if rank == 0:
         segs = B * world * args.steps
@@ -387,6 +419,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "segments_per_s": seg_s, "output_finite": out_ok, "rccl_ranks": rccl_ranks,
+            "parity_spot_check": (spot_ok if spot is not None else None), "parity_spot_check_detail": spot,
+            "build_flags": ops.build_flags(),
             "config": {"workload": ("joint audio+tactile ProposedEval.forward_eval (compare_dacvsproposal_5 config: "
                                     "2x DAC-24k encoder, 32x1024x8 audio RVQ, CrossPredictor AR x5 chunks, "
                                     f"RVQ {args.books}x{args.embed}x96, DAC-24k decoder)") if not tact else
@@ -408,7 +442,9 @@ def main():
             gf = GFLOP_PER_SEGMENT[args.workload]
             line["path_tflops"] = seg_s * gf * 1e-3 / world            # per GPU, algorithmic
         if unprof_ms is not None:
-            line["ms_per_step_without_kernel_events"] = unprof_ms     # rank 0, untimed extra steps after the measured region
+            # rank 0, a SEPARATE measurement: min(steps, 3) further steps behind a barrier, after the measured region (for the
+            # train workload these steps go on updating the model and codebooks, so it is a like-for-like cost, not the same data)
+            line["ms_per_step_without_kernel_events"] = unprof_ms
         ms_ = torch.cuda.memory_stats(dev)
         line["device_memory"] = {"peak_allocated_GB": ms_.get("allocated_bytes.all.peak", 0) / 1e9,
                                  "peak_reserved_GB": ms_.get("reserved_bytes.all.peak", 0) / 1e9,
@@ -467,6 +503,8 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if not spot_ok:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -98,6 +98,11 @@ def conv1d(x, wp, cout, ks, bias=None, stride=1, dil=1, pad=0, alpha_in=None, re
     return out if alpha_dual is None else (out, y2)
 
 
+def build_flags() -> int:
+    """mvq_build_flags() (include/mvq.h): 0 = product build with no A/B override in the environment."""
+    return _lib.build_flags()
+
+
 def profile_begin() -> None:
     """Start bracketing every conv / residual-unit kernel launch with HIP events on its launch stream (include/mvq.h)."""
     check(_lib.lib().mvq_profile_begin(), "mvq_profile_begin")

@@ -21,13 +21,23 @@ def model(dev):
     return sd, build_proposed(sd, rvq_books=8, rvq_embed=512, device=dev)
 
 
-def test_full_segment_against_oracle(model, orc, dev):
-    """configs[2] at its real size (24 000 + 24 000 samples -> 75 tokens -> 23 992 samples), B = 1, vs the oracle."""
-    from multimodal_vqvae_compression_audio_tactile_amd import psnr_batch, synth
-    sd, net = model
+@pytest.fixture(scope="module")
+def oracle_segment(model, orc):
+    """One full 1-s segment pair through the C oracle (joint path: latents + waveform; tactile-only chain: waveform)."""
+    from multimodal_vqvae_compression_audio_tactile_amd import synth
+    sd, _ = model
     a, t = synth.audio_segments(1, seed=21), synth.tactile_segments(1, seed=21)
-    want_z, aux = orc.proposed_encode_latents(_np(sd), a.numpy(), t.numpy(), return_aux=True)
+    want_z = orc.proposed_encode_latents(_np(sd), a.numpy(), t.numpy())
     want_y = orc.dac_decoder(_np(sd), want_z, prefix="T_DEC.")
+    want_y_tact = orc.proposed_forward_eval(_np(sd), None, t.numpy(), tactile_only=True)
+    return a, t, want_z, want_y, want_y_tact
+
+
+def test_full_segment_against_oracle(model, oracle_segment, orc, dev):
+    """configs[2] at its real size (24 000 + 24 000 samples -> 75 tokens -> 23 992 samples), B = 1, vs the oracle."""
+    from multimodal_vqvae_compression_audio_tactile_amd import psnr_batch
+    sd, net = model
+    a, t, want_z, want_y, _ = oracle_segment
     z = net.encode_latents(a.to(dev), t.to(dev))
     y = net.T_DEC(z)
     assert z.shape == (1, 1024, 75) and y.shape == (1, 1, 23992)
@@ -51,6 +61,42 @@ def test_batch_independence_and_reproducibility_at_bench_size(model, dev):
         assert torch.equal(net.forward_eval(a[i:i + 1], t[i:i + 1]), y[i:i + 1])
     z = net.encode_latents(a[:4], t[:4])
     assert torch.equal(net.T_DEC(z), y[:4])                                    # split encode / decode API == forward_eval
+
+
+def test_headline_batch_256_is_tied_to_the_oracle(model, oracle_segment, dev):
+    """The configuration bench.py's headline is quoted on (SURVEY 8d configs 2 / 3, B = 256: single-stream encoders, 23 full
+    column tiles + tail split launches, packed latent rows with a full 32 x 8 layout): rows of the 256-segment batch that hold
+    the oracle-checked segment must carry the ORACLE's waveform bit for bit, wherever they sit in the batch; other rows must
+    equal their own B = 1 run; same for the tactile-only chain."""
+    from multimodal_vqvae_compression_audio_tactile_amd import synth
+    sd, net = model
+    a1, t1, want_z, want_y, want_y_tact = oracle_segment
+    B = 256
+    a, t = synth.audio_segments(B, seed=5), synth.tactile_segments(B, seed=5)
+    planted = (3, 129, B - 1)                         # first packed row, a middle one, the last column of the last row
+    for i in planted:
+        a[i], t[i] = a1[0], t1[0]
+    a, t = a.to(dev), t.to(dev)
+    y = net.forward_eval(a, t)
+    assert y.shape == (B, 1, 23992) and torch.isfinite(y).all()
+    want = torch.from_numpy(want_y).to(dev)
+    for i in planted:
+        assert torch.equal(y[i:i + 1], want), f"joint path, segment {i} of the 256-segment batch differs from the oracle"
+    for i in (0, 77, 200):                            # batch mates are irrelevant (B = 1 runs other tiles / launch plans)
+        assert torch.equal(net.forward_eval(a[i:i + 1], t[i:i + 1]), y[i:i + 1])
+    z = net.encode_latents(a, t)
+    zw = torch.from_numpy(want_z).to(dev)
+    for i in planted:
+        assert torch.equal(z[i:i + 1], zw)
+    del y, z
+    # tactile-only chain (configs[1]) at the same size
+    yt = net.forward_eval_tactile_only(t)
+    assert yt.shape == (B, 1, 23992)
+    wt = torch.from_numpy(want_y_tact).to(dev)
+    for i in planted:
+        assert torch.equal(yt[i:i + 1], wt), f"tactile chain, segment {i} of the 256-segment batch differs from the oracle"
+    for i in (0, 200):
+        assert torch.equal(net.forward_eval_tactile_only(t[i:i + 1]), yt[i:i + 1])
 
 
 def test_conv_power_of_two_linearity(dev):

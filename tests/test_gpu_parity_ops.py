@@ -446,6 +446,7 @@ print(hashlib.sha256(b"".join(o.cpu().numpy().tobytes() for o in outs)).hexdiges
         env = {k: v for k, v in os.environ.items() if k != "MVQ_NO_DMA"}
         if no_dma:
             env["MVQ_NO_DMA"] = "1"
+            env["MVQ_ALLOW_TIMING_BUILD"] = "1"          # an A/B knob in the environment: mvq_build_flags() != 0, loading is opt-in
         res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
         digests.append(res.stdout.strip().splitlines()[-1])

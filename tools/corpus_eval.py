@@ -53,6 +53,10 @@ def main():
     import multimodal_vqvae_compression_audio_tactile_amd as mvq
     from multimodal_vqvae_compression_audio_tactile_amd import dist as mdist, synth
     dist, ranks = None, None
+    if args.force_collectives and not all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
+        raise SystemExit("corpus_eval.py --force-collectives needs the launcher's rendezvous variables; run it as\n"
+                         "  python3 -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node=1 "
+                         "tools/corpus_eval.py --force-collectives ...")
     if world > 1 or args.force_collectives:
         # BASELINE.json configs[3]: "... frame-sharded across 8 MI355X via RCCL".  Ranks on distinct devices bring up an RCCL
         # group that must pass the all-reduce probe (fatal otherwise, no fallback); gloo only in the one-device rehearsal.
