@@ -308,7 +308,10 @@ struct ConvCfg {
     static constexpr int BN = 32 * NT * WAVES_N;
     static constexpr int KC = CK * KS;                                  // K elements per chunk
     static constexpr int XT = (BN - 1) * STRIDE + (KS - 1) * DIL + 1;    // input samples per row
-    static constexpr int XV = (XT + 3 + 3) / 4;                          // float4 per row (aligned start, shift <= 3)
+    // a 1x1 conv (no padding: checked by the launcher) starts every tile on a 16-byte boundary of its row, so its rows need no
+    // alignment slack: exactly BN / 4 pieces -- for the 128 x 128 tile that is 4 instead of 5 LDS-DMA instructions per chunk
+    static constexpr bool XALIGNED = (KS == 1 && STRIDE == 1);
+    static constexpr int XV = XALIGNED ? (XT + 3) / 4 : (XT + 3 + 3) / 4; // float4 per row (aligned start, shift <= 3)
     static constexpr int XTP = XV * 4 + 4;                               // row pitch (floats), multiple of 4
     static constexpr int W_FLOATS = KC * BM;
     static constexpr int X_FLOATS = CK * XTP;
@@ -319,7 +322,16 @@ struct ConvCfg {
     // when that is what keeps the block's LDS footprint down (more co-resident blocks per CU)
     static constexpr int EH = ((UPS == 0 || 32 % (UPS ? UPS : 1) == 0) && MT % 2 == 0 && CT_FLOATS > STAGE_FLOATS) ? 2 : 1;
     static constexpr int CTH_FLOATS = CT_FLOATS / EH;
-    static constexpr int LDS_FLOATS = STAGE_FLOATS > CTH_FLOATS ? STAGE_FLOATS : CTH_FLOATS;
+    // epilogue row table Tb = [bias | alpha_out | alpha2][BM], filled once per block right behind the epilogue tile (inside the
+    // staging region where that is the larger one, so the K-loop footprint -- blocks per CU -- does not change)
+    // Only tiles with the regular quad mapping of the epilogue use it (REG_GEOM: NTHR a multiple of the BN / 4 quads of a row).
+    // LDS is allocated in 1 280-byte granules on this chip (measured: a 54 272-byte block runs two per CU, 53 568 three), so
+    // the 128 x 96 tiles (52 736 bytes, three blocks per CU) cannot afford the table and keep the generic epilogue.
+    static constexpr bool REG_GEOM = (UPS == 0) && ((64 * WAVES_M * WAVES_N) % (BN / 4) == 0) && (32 % ((64 * WAVES_M * WAVES_N) / (BN / 4)) == 0);
+    static constexpr int TB_FLOATS = REG_GEOM ? 3 * BM : 0;
+    static constexpr int EPI_FLOATS = CTH_FLOATS + TB_FLOATS;
+    static constexpr int EPI_FLOATS_FUSE = CT_FLOATS + TB_FLOATS;
+    static constexpr int LDS_FLOATS = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
     // Waves per SIMD the register allocator is asked to leave room for (= blocks per CU for a 4-wave block): 3 where the
     // block's LDS footprint fits three times into 160 KB (the kernels then need 112-165 VGPRs of the 168 allowed, no
     // spills).  Four (128 VGPRs) was measured on the 7-tap 128x128 tile: 7 dwords of scratch, +1.5 % in isolation, nothing
@@ -327,16 +339,16 @@ struct ConvCfg {
     static constexpr bool FOUR_WAVES = WAVES_M * WAVES_N == 4;
     static constexpr int MIN_WPE = (FOUR_WAVES && LDS_FLOATS * 4 <= 53 * 1024 && !(WAVES_N == 4 && NT == 2)) ? 3
                                                                                                                 : (WAVES_M * WAVES_N) / 2;
-    static constexpr int LDS_FLOATS_FUSE = STAGE_FLOATS > CT_FLOATS ? STAGE_FLOATS : CT_FLOATS;   // fused unit: full tile
+    static constexpr int LDS_FLOATS_FUSE = STAGE_FLOATS > EPI_FLOATS_FUSE ? STAGE_FLOATS : EPI_FLOATS_FUSE;   // fused unit: full tile
     static constexpr int MIN_WPE_FUSE = (FOUR_WAVES && (LDS_FLOATS_FUSE + 5 * BM) * 4 * 3 <= 160 * 1024) ? 3 : (WAVES_M * WAVES_N) / 2;
     // LDS-DMA ring: a stage is the weight chunk followed by the activation chunk with dense rows (pitch XV*4), three stages
     static constexpr int XV4 = XV * 4;
     static constexpr int DMA_STAGE_FLOATS = W_FLOATS + CK * XV4;
     static constexpr int DMA_NV = DMA_STAGE_FLOATS / 4;                  // float4 pieces per stage
     static constexpr int DMA_NU = (DMA_NV + 64 * WAVES_M * WAVES_N - 1) / (64 * WAVES_M * WAVES_N);   // DMA instructions per wave per chunk
-    static constexpr int LDS_FLOATS_DMA = 3 * DMA_STAGE_FLOATS > CTH_FLOATS ? 3 * DMA_STAGE_FLOATS : CTH_FLOATS;
+    static constexpr int LDS_FLOATS_DMA = 3 * DMA_STAGE_FLOATS > EPI_FLOATS ? 3 * DMA_STAGE_FLOATS : EPI_FLOATS;
     // fused unit fed by LDS-DMA (its input arrives pre-snaked): the 3-stage ring, then the full intermediate / epilogue tile
-    static constexpr int LDS_FLOATS_FUSE_DMA = 3 * DMA_STAGE_FLOATS > CT_FLOATS ? 3 * DMA_STAGE_FLOATS : CT_FLOATS;
+    static constexpr int LDS_FLOATS_FUSE_DMA = 3 * DMA_STAGE_FLOATS > EPI_FLOATS_FUSE ? 3 * DMA_STAGE_FLOATS : EPI_FLOATS_FUSE;
     static constexpr int W_VEC = W_FLOATS / 4;                           // float4 per chunk
     static constexpr int NTHR = 64 * WAVES_M * WAVES_N;                  // threads per block
     static constexpr int W_PER_THREAD = (W_VEC + NTHR - 1) / NTHR;
@@ -921,17 +933,59 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     constexpr bool PRE_RES = (UPS == 0) && (NVQ % C::NTHR == 0) && (NVQ / C::NTHR <= 16);
 #endif
     constexpr int RES_IT = PRE_RES ? NVQ / C::NTHR : 1;
+    // REGULAR quad mapping (every 128- / 64- / 256-column tile): NTHR is a multiple of the BN / 4 quads of a tile row, so a thread
+    // keeps ONE column quad and its rows advance by the constant RSTEP per iteration.  Everything that depends only on the column
+    // (bounds, the zero-tail / packed-gap mask) is then per-thread state, the row of iteration `it` is r0 + a compile-time
+    // constant (LDS reads of the tile and of the row tables take immediate offsets), and global addresses are a uniform 64-bit
+    // base per block + a 32-bit per-thread offset that advances by a scalar -- the quad's vector work is the arithmetic itself.
+    // (Before: e / (BN/4), the tile-row shuffle, a 64-bit address and three global loads of bias / alpha per quad; vector
+    // instructions are additive to fp32 MFMA time on this chip)
+    constexpr int QPR = C::BN / 4;
+    constexpr bool REG = PRE_RES && C::REG_GEOM;
+    constexpr int RSTEP = REG ? C::NTHR / QPR : 1;
+    const int q_c4 = REG ? tid % QPR : 0, q_r0 = REG ? tid / QPR : 0;
+    // row of the block tile that iteration `it` of the regular mapping handles, minus q_r0: a constant after unrolling
+    auto reg_k = [&](int it, int pass) __attribute__((always_inline)) {
+        const int lr = it * RSTEP;                                     // local row (of this pass) of the thread with q_r0 == 0
+        if (EHP == 1) return lr;
+        const int g = lr >> 5;
+        return ((g / MTH) * MT + pass * MTH + (g % MTH)) * 32 + (lr & 31);
+    };
+    const size_t blk_off = ((size_t)b * a.Cout + m0) * a.Tout + n0;   // uniform: element (b, m0, n0)
+    const unsigned q_t0 = (unsigned)(q_r0 * a.Tout + 4 * q_c4);
+    const bool q_nok = n0 + 4 * q_c4 < a.Ncols;
     f32x4 res_q[RES_IT];
     if (PRE_RES && has_res && a.ovec4) {
+        if constexpr (REG) {
+            const float* resb = a.residual + blk_off;
 #pragma unroll
-        for (int it = 0; it < RES_IT; ++it) {
-            const int e = tid + it * C::NTHR;
-            const int row = e / (C::BN / 4);
-            const int c4 = e - row * (C::BN / 4);
-            const int m = m0 + tile_row_of(row, hp), n = n0 + 4 * c4;
-            const bool ok = m < a.Mrows && n < a.Ncols;
-            const size_t off = ((size_t)b * a.Cout + (ok ? m : 0)) * a.Tout + (ok ? n : 0);
-            res_q[it] = *reinterpret_cast<const f32x4*>(a.residual + off);
+            for (int it = 0; it < RES_IT; ++it) {
+                const int k = reg_k(it, hp);
+                const bool ok = q_nok && m0 + q_r0 + k < a.Mrows;
+                res_q[it] = *reinterpret_cast<const f32x4*>(resb + (ok ? q_t0 + (unsigned)(k * a.Tout) : 0u));
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < RES_IT; ++it) {
+                const int e = tid + it * C::NTHR;
+                const int row = e / (C::BN / 4);
+                const int c4 = e - row * (C::BN / 4);
+                const int m = m0 + tile_row_of(row, hp), n = n0 + 4 * c4;
+                const bool ok = m < a.Mrows && n < a.Ncols;
+                const size_t off = ((size_t)b * a.Cout + (ok ? m : 0)) * a.Tout + (ok ? n : 0);
+                res_q[it] = *reinterpret_cast<const f32x4*>(a.residual + off);
+            }
+        }
+    }
+    // epilogue row table (bias | alpha_out | alpha2 of this block's rows) behind the tile: one fill per block
+    float* const Tb = smem + (FUSE ? C::CT_FLOATS : C::CTH_FLOATS);
+    if (UPS == 0 && REG && hp == 0) {
+        for (int r = tid; r < C::BM; r += C::NTHR) {
+            int m = m0 + r;
+            m = m < a.Mrows ? m : a.Mrows - 1;
+            Tb[r] = ep_bias ? ep_bias[m] : 0.0f;
+            Tb[C::BM + r] = a.alpha_out ? a.alpha_out[m] : 1.0f;
+            Tb[2 * C::BM + r] = a.y2 ? a.alpha2[m] : 1.0f;
         }
     }
     __syncthreads();
@@ -982,7 +1036,56 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     *reinterpret_cast<f32x4*>(a.y + off) = v;
                 }
             };
-            if (PRE_RES) {
+            if constexpr (REG) {
+                const int n = n0 + 4 * q_c4;
+                int nz = (a.tvalid && n + 4 > a.tvalid) ? n + 4 - a.tvalid : 0;               // trailing pad columns of this thread's quads
+                if (a.tper) {                                         // packed rows: the gap columns of every period
+                    const int nn = n - (int)__umulhi((unsigned)n, a.tper_magic) * a.tper;
+                    nz = nn + 4 > a.tper_valid ? (nn >= a.tper_valid ? 4 : nn + 4 - a.tper_valid) : 0;
+                }
+                float* const yb = a.y + blk_off;
+                float* const y2b = a.y2 ? a.y2 + blk_off : nullptr;
+                const float* const dsb = a.dsn_src ? a.dsn_src + blk_off : nullptr;
+                const float* const ctq = Ct + q_r0 * C::BNP + 4 * q_c4;
+                const float* const tbq = Tb + q_r0;
+                const float* const epq = Ep + q_r0;
+#pragma unroll
+                for (int it = 0; it < RES_IT; ++it) {
+                    const int k = reg_k(it, hp);                       // compile-time after unrolling
+                    const int trow = q_r0 + k;
+                    if (q_nok && m0 + trow < a.Mrows) {
+                        const unsigned toff = q_t0 + (unsigned)(k * a.Tout);
+                        const float bv = tbq[k];
+                        f32x4 v = *reinterpret_cast<const f32x4*>(ctq + it * RSTEP * C::BNP);
+                        v.x = v.x + bv; v.y = v.y + bv; v.z = v.z + bv; v.w = v.w + bv;
+                        if (a.dsn_src) {
+                            const float ad = a.dsn_alpha[m0 + trow], id = epq[2 * C::BM + k];
+                            const f32x4 sv = *reinterpret_cast<const f32x4*>(dsb + toff);
+                            v.x = v.x * det_dsnake(sv.x, ad, id); v.y = v.y * det_dsnake(sv.y, ad, id);
+                            v.z = v.z * det_dsnake(sv.z, ad, id); v.w = v.w * det_dsnake(sv.w, ad, id);
+                        }
+                        if (has_res) {
+                            const f32x4 rv = res_q[it];
+                            v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
+                        }
+                        if (a.y2) {
+                            const float a2 = tbq[2 * C::BM + k], i2 = epq[C::BM + k];
+                            f32x4 w = {det_snake(v.x, a2, i2), det_snake(v.y, a2, i2), det_snake(v.z, a2, i2), det_snake(v.w, a2, i2)};
+                            if (nz > 0) { w.w = 0.0f; if (nz > 1) w.z = 0.0f; if (nz > 2) w.y = 0.0f; if (nz > 3) w.x = 0.0f; }
+                            *reinterpret_cast<f32x4*>(y2b + toff) = w;
+                        }
+                        if (snake_out) {
+                            const float al = tbq[C::BM + k], inv = epq[k];
+                            v.x = det_snake(v.x, al, inv); v.y = det_snake(v.y, al, inv);
+                            v.z = det_snake(v.z, al, inv); v.w = det_snake(v.w, al, inv);
+                        }
+                        if (do_tanh) { v.x = det_tanh(v.x); v.y = det_tanh(v.y); v.z = det_tanh(v.z); v.w = det_tanh(v.w); }
+                        if (do_gelu) { v.x = det_gelu(v.x); v.y = det_gelu(v.y); v.z = det_gelu(v.z); v.w = det_gelu(v.w); }
+                        if (nz > 0) { v.w = 0.0f; if (nz > 1) v.z = 0.0f; if (nz > 2) v.y = 0.0f; if (nz > 3) v.x = 0.0f; }
+                        *reinterpret_cast<f32x4*>(yb + toff) = v;
+                    }
+                }
+            } else if (PRE_RES) {
 #pragma unroll
                 for (int it = 0; it < RES_IT; ++it) quad(tid + it * C::NTHR, it);
             } else {
@@ -1112,6 +1215,7 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
     using C = ConvCfg<KS, STRIDE, DIL, CK, MT, NT, WAVES_M, WAVES_N, UPS>;
     ConvArgs a = a_in;
     if (a.Cin % CK != 0 || a.Mpad % C::BM != 0) return hipErrorInvalidValue;
+    if (C::XALIGNED && (a.pad != 0 || a.n_base % 4 != 0)) return hipErrorInvalidValue;   // the 1x1 tiling assumes 16-byte tile starts
     if (a.name_out) {
         snprintf(a.name_out, a.name_len, "conv1d_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", KS, STRIDE, DIL, CK, MT, NT,
                  WAVES_M, WAVES_N, UPS);

@@ -141,7 +141,10 @@ __device__ __forceinline__ float det_sin_turns(float t)
     p = dfma(v, p, -5.167712688446045f);
     p = dfma(v, p, 3.1415927410125732f);
     const float s = f * p;
-    return ((int)n & 1) ? -s : s;
+    // parity of n without converting an unbounded float to int (that conversion saturates on the device and is undefined
+    // behaviour on the host for |n| >= 2^31): n is odd exactly when n/2 is not an integer; every |n| >= 2^24 is even
+    const float hn = 0.5f * n;
+    return (hn != __builtin_rintf(hn)) ? -s : s;
 }
 
 // d snake(x)/dx = 1 + (alpha/(alpha+1e-9)) * sin(2*alpha*x)   (backward of Snake1d); 2*alpha*x = pi * (2t)

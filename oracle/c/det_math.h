@@ -163,7 +163,10 @@ static inline float om_sin_turns(float t)
     p = om_fma(v, p, -5.167712688446045f);
     p = om_fma(v, p, 3.1415927410125732f);
     float s = f * p;
-    return ((int)n & 1) ? -s : s;
+    /* parity of n without a float -> int conversion of an unbounded value (undefined behaviour for |n| >= 2^31): n is odd
+     * exactly when n/2 is not an integer; every |n| >= 2^24 is even */
+    float hn = 0.5f * n;
+    return (hn != rintf(hn)) ? -s : s;
 }
 
 /* d snake(x)/dx = 1 + (alpha/(alpha+1e-9)) * sin(2*alpha*x)   (backward of Snake1d) */

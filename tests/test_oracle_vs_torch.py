@@ -44,6 +44,35 @@ def test_det_math_accuracy(orc):
     assert orc.exp(np.array([-200.0], np.float32))[0] == 0
 
 
+def test_snake_large_phase_and_small_alpha_error_budget(orc):
+    """Snake / its derivative outside the activation-scale box of test_det_math_accuracy: |alpha x| up to a few hundred and
+    alpha near 0, against float64 with an explicit budget.  The phase in turns t = x * (alpha / pi) rounds twice (alpha/pi, then
+    the product): |dt| <= 2^-23 |t| (two half-ulp roundings), i.e. a phase error of pi |dt| <= 3.8e-7 |t| radians; d/dphase of
+    sin^2 is at most 1, and the result is divided by alpha.  Budget: (3.8e-7 |t| + 3e-7) / alpha + 1 ulp of the output."""
+    r = np.random.default_rng(5)
+    for amax, xmax in ((3.0, 100.0), (8.0, 60.0), (0.05, 6.0), (1e-3, 50.0)):
+        al = r.uniform(amax / 10, amax, 64).astype(np.float32)
+        xs = r.uniform(-xmax, xmax, (1, 64, 3000)).astype(np.float32)
+        a64, x64 = al[None, :, None].astype(np.float64), xs.astype(np.float64)
+        want = x64 + np.sin(a64 * x64) ** 2 / (a64 + 1e-9)
+        got = orc.snake(xs, al).astype(np.float64)
+        t = np.abs(a64 * x64) / np.pi
+        budget = (3.8e-7 * t + 3e-7) / a64 + 1.2e-7 * np.abs(want)
+        assert (np.abs(got - want) <= budget).all(), (amax, xmax, float((np.abs(got - want) / budget).max()))
+        # derivative 1 + alpha/(alpha + 1e-9) sin(2 alpha x): phase 2 pi t, slope at most 2 per radian of phase error
+        g = np.ones_like(xs)
+        dgot = orc.mul_dsnake(g, xs, al).astype(np.float64)
+        dwant = 1.0 + a64 / (a64 + 1e-9) * np.sin(2 * a64 * x64)
+        dbudget = 2 * (3.8e-7 * 2 * t + 3e-7) + 2.4e-7
+        assert (np.abs(dgot - dwant) <= dbudget).all(), (amax, xmax, float((np.abs(dgot - dwant) / dbudget).max()))
+    # the sign rule of sin(pi t) for huge |t| (no float -> int conversion of an unbounded value): every |t| >= 2^24 is an even
+    # integer in fp32, so sin(pi t) = +-0 exactly, on both sides of 2^31
+    big = np.array([2.0 ** 24, 2.0 ** 31, -2.0 ** 31, 3.0e9, -3.0e9, 1.0e20], np.float32)
+    assert (orc.sin_turns(big) == 0).all() and (orc.sin2_turns(big) == 0).all()
+    odd = np.array([1.5, 2.5, -1.5, 16777215.0 - 0.0], np.float32)            # rint ties to even: n = 2, 2, -2; 2^24 - 1 is odd
+    assert np.allclose(orc.sin_turns(odd[:3]), [-1.0, 1.0, 1.0], atol=3e-7) and orc.sin_turns(odd[3:])[0] == 0
+
+
 def test_conv_stacks_match_torch(orc):
     from multimodal_vqvae_compression_audio_tactile_amd import synth
     from oracle import dac24_torch as T
