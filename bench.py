@@ -202,6 +202,28 @@ def pmc_traffic_table():
     return tab, src
 
 
+def vq_lds_table():
+    """profiles/pmc_vq_lds.json (tools/pmc_vq.py: SQ counters of the codebook-search kernels from a rocprofv3 --pmc pass of this
+    same command) -> the `vq` object of the line: LDS instructions per global read, LDS share of the operand fetches, bank-conflict
+    fraction and LDS-array busy share of peak per kernel, with the stamp that says whether the kernels changed since."""
+    f = ROOT / "profiles" / "pmc_vq_lds.json"
+    if not f.exists():
+        return None
+    try:
+        tab = json.loads(f.read_text())
+    except Exception:
+        return None
+    meta = tab.pop("_meta", {})
+    from tools.pmc_traffic import csrc_digest
+    now = csrc_digest(ROOT)
+    keys = ("launches", "lds_per_vmem_rd", "lds_operand_share", "lds_bank_conflict_frac", "lds_busy_frac_of_peak")
+    return {"bound": "lds", "kernels": {k: {q: v.get(q) for q in keys} for k, v in tab.items()},
+            "peak": "one LDS access cycle per CU per clock (128 B ds_read_b32, 256 B b64/b128; MI355X guide, LDS table)",
+            "source": {"file": "profiles/pmc_vq_lds.json", "profiled_at_commit": meta.get("commit"),
+                       "csrc_sha16_profiled": meta.get("csrc_sha16"), "csrc_sha16_now": now,
+                       "kernels_unchanged_since_profile": bool(meta.get("csrc_sha16")) and meta.get("csrc_sha16") == now}}
+
+
 def latency_b1(mvq, synth, dev, books, embed, sd):
     """B = 1 latency in the reference's own protocol (Evaluation/dac_vcpwq_proposed6_latency.py:489-525): 1 s of zeros,
     3 warm-ups, 10 repeats, device synchronised before each clock read; encode_latents and T_DEC timed separately -- eager
@@ -485,6 +507,10 @@ def main():
                     line["conv_stack"]["hbm"] = {"achieved_GBps": by / conv_s * 1e-9, "peak_GBps": 8000.0,
                                                  "frac": by / conv_s * 1e-9 / 8000.0,
                                                  "GB_per_step": by / args.steps * 1e-9, "source": pmc_src}
+        if not train:
+            vq = vq_lds_table()
+            if vq:
+                line["vq"] = vq
         if world == 1 and not train and not args.no_latency:
             try:
                 line["latency_b1"] = latency_b1(mvq, synth, dev, args.books, args.embed, sd)

@@ -12,8 +12,9 @@ The modules below are ``torch.nn.Module`` parameter containers with the upstream
 so that reference checkpoints (``A_ENC.* / A_QUANT.* / T_ENC.* / T_DEC.*``) load unchanged.  ``forward`` never
 touches torch math: it walks a fused launch plan over the C ABI (weight-norm folded and packed once, Snake1d
 fused into the neighbouring conv's prologue/epilogue, residual adds and tanh fused into epilogues).
-Parameters are frozen by the reference (``requires_grad_(False)``, Training/...5.py:283-284); autograd through
-the decoder input (training config) is not part of this round.
+Parameters are frozen by the reference (``requires_grad_(False)``, Training/...5.py:283-284).  With autograd enabled
+and an input that requires a gradient (the training config, ...5.py:322,393) ``Decoder.forward`` runs a saving forward and
+a HIP backward w.r.t. its input (``_DecoderInputGrad``); the saved forward is released layer by layer during that backward.
 """
 from __future__ import annotations
 
@@ -327,17 +328,25 @@ class Decoder(nn.Module):
         derivatives fused into their epilogues (83 GFLOP per segment, like the forward)."""
         m = self.model
         nblk = len(m) - 4
-        g = ops.mul_dtanh(gy, saved["y"])
-        g = m[nblk + 2].dgrad(g, saved["hl"].shape[-1], dsnake_src=saved["hl"], dsnake_alpha=m[nblk + 1].flat())
+        # every saved activation is released as soon as its layer's gradient has been queued (pop, not index): the backward's
+        # footprint shrinks as it walks down the stack instead of holding the whole forward until the step ends
+        y = saved.pop("y")
+        g = ops.mul_dtanh(gy, y)
+        del y
+        hl = saved.pop("hl")
+        g = m[nblk + 2].dgrad(g, hl.shape[-1], dsnake_src=hl, dsnake_alpha=m[nblk + 1].flat())
+        del hl
         for i in range(nblk, 0, -1):
             blk = m[i].block
             for j in (4, 3, 2):
                 ru = blk[j].block
-                x, t7 = saved[f"b{i}.r{j}.x"], saved[f"b{i}.r{j}.t7"]
+                x, t7 = saved.pop(f"b{i}.r{j}.x"), saved.pop(f"b{i}.r{j}.t7")
                 g1 = ru[3].dgrad(g, t7.shape[-1], dsnake_src=t7, dsnake_alpha=ru[2].flat())
                 g = ru[1].dgrad(g1, x.shape[-1], dsnake_src=x, dsnake_alpha=ru[0].flat(), residual=g)
-            xin = saved[f"b{i}.x"]
+                del x, t7, g1
+            xin = saved.pop(f"b{i}.x")
             g = blk[1].dgrad(g, xin.shape[-1], dsnake_src=xin, dsnake_alpha=blk[0].flat())
+            del xin
         return m[0].dgrad(g, saved["z_len"])
 
     def forward(self, z):
@@ -422,12 +431,20 @@ class _DecoderInputGrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, dec):
         y, saved = dec.forward_saving(z.detach())
+        # `saved` must not hold the tensor object this Function RETURNS: the returned y gets this node as its grad_fn, and
+        # node -> ctx.saved -> y -> grad_fn -> node is a reference cycle only Python's cyclic collector can break -- the whole
+        # saved forward (45 GB at 256 segments) then outlives the step until a full collection happens to run (measured:
+        # +45 GB per step, 145 GB peak after three steps).  A detached alias shares the storage without the back pointer.
+        saved["y"] = y.detach()
         ctx.dec, ctx.saved = dec, saved
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        return ctx.dec.backward_input(ctx.saved, gy.contiguous()), None
+        saved, ctx.saved = ctx.saved, None                       # consumed once: nothing survives the backward
+        if saved is None:
+            raise RuntimeError("Decoder input-gradient: backward called twice (the saved forward is released by the first call)")
+        return ctx.dec.backward_input(saved, gy.contiguous()), None
 
 
 class VectorQuantize(nn.Module):

@@ -4,7 +4,7 @@
 # Writes everything under gpurun_out/<round-tag>prof/; the summaries to keep are copied into profiles/ by hand afterwards.
 # Counter passes are separate runs with --kernel-trace only (no sys/hip/hsa trace domains), the program itself directly after "--".
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 COMMIT=${2:-unknown}
 OUT=gpurun_out/${TAG}prof
 mkdir -p "$OUT"
@@ -22,6 +22,13 @@ python3 tools/pmc_traffic.py "$OUT/fetch" "$OUT/write" "$OUT/pmc_traffic.json" "
     rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-latency > "$OUT/pmc_traffic.txt" || exit 32
 # the bench reads profiles/pmc_traffic.json: install the fresh table BEFORE the stored bench lines are produced
 cp "$OUT/pmc_traffic.json" profiles/pmc_traffic.json
+
+echo "[3b] SQ counters of the codebook-search kernels (LDS instructions per global read, bank conflicts, LDS busy share)"
+VQ_CMD="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv \
+    -d "$OUT/vq" -- $VQ_CMD > /dev/null 2> "$OUT/vq.err" || exit 33
+python3 tools/pmc_vq.py "$OUT/vq" "$OUT/pmc_vq_lds.json" "$COMMIT" rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE -- $VQ_CMD > "$OUT/pmc_vq_lds.txt" || exit 34
+cp "$OUT/pmc_vq_lds.json" profiles/pmc_vq_lds.json
 
 echo "[4/8] SQ counters: dominant k7 kernel (dec.b0, d = 3) and one fused unit (enc.b1, d = 3)"
 for L in dec.b0.k7d3 enc.b1.RUd3; do

@@ -20,6 +20,6 @@ def t(fn, n=3):
 ms_f, _ = t(lambda: dec._forward_fast(z))
 ms_s, (y, saved) = t(lambda: dec.forward_saving(z))
 gy = torch.randn_like(y)
-ms_b, gz = t(lambda: dec.backward_input(saved, gy))
+ms_b, gz = t(lambda: dec.backward_input(dict(saved), gy))
 gf = 83.41 * B
 print(f"B={B}: inference forward {ms_f:.1f} ms ({gf/ms_f:.1f} TF) | saving forward {ms_s:.1f} ms ({gf/ms_s:.1f} TF) | backward-input {ms_b:.1f} ms ({gf/ms_b:.1f} TF)")
