@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "det_math.hpp"
 #include "kernels_small.hpp"
 
@@ -302,6 +303,8 @@ struct AsmOperandLoop {
     }
 };
 
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+
 template <int KS, int STRIDE, int DIL, int CK, int MT, int NT, int WAVES_M, int WAVES_N, int UPS>
 struct ConvCfg {
     static constexpr int BM = 32 * MT * WAVES_M;
@@ -322,13 +325,20 @@ struct ConvCfg {
     // when that is what keeps the block's LDS footprint down (more co-resident blocks per CU)
     static constexpr int EH = ((UPS == 0 || 32 % (UPS ? UPS : 1) == 0) && MT % 2 == 0 && CT_FLOATS > STAGE_FLOATS) ? 2 : 1;
     static constexpr int CTH_FLOATS = CT_FLOATS / EH;
-    // epilogue row table Tb = [bias | alpha_out | alpha2][BM], filled once per block right behind the epilogue tile (inside the
-    // staging region where that is the larger one, so the K-loop footprint -- blocks per CU -- does not change)
-    // Only tiles with the regular quad mapping of the epilogue use it (REG_GEOM: NTHR a multiple of the BN / 4 quads of a row).
-    // LDS is allocated in 1 280-byte granules on this chip (measured: a 54 272-byte block runs two per CU, 53 568 three), so
-    // the 128 x 96 tiles (52 736 bytes, three blocks per CU) cannot afford the table and keep the generic epilogue.
-    static constexpr bool REG_GEOM = (UPS == 0) && ((64 * WAVES_M * WAVES_N) % (BN / 4) == 0) && (32 % ((64 * WAVES_M * WAVES_N) / (BN / 4)) == 0);
-    static constexpr int TB_FLOATS = REG_GEOM ? 3 * BM : 0;
+    // epilogue row table Tb, filled once per block right behind the epilogue tile (inside the staging region where that is the
+    // larger one, so the K-loop footprint -- blocks per CU -- does not change)
+    // Regular quad mapping of the epilogue (conv1d_mfma_body): the block's NTHR threads form CQ column-quad lanes x RSTEP rows,
+    // CQ = gcd(BN / 4, NTHR); a thread keeps its JN = (BN / 4) / CQ column quads (one for the 128- / 64- / 256-column tiles,
+    // three for the 96- and 192-column ones) and its rows advance by RSTEP per step.  Needs RSTEP | 32 (a step never leaves
+    // its 32-row accumulator group) -- true for every stride-1 / strided tile in use.
+    static constexpr int QPR = BN / 4;
+    static constexpr int CQ = cgcd(QPR, 64 * WAVES_M * WAVES_N);
+    static constexpr int JN = QPR / CQ;
+    static constexpr int RSTEP = (64 * WAVES_M * WAVES_N) / CQ;
+    static constexpr bool REG_GEOM = (UPS == 0) && (32 % RSTEP == 0);
+    // Tb = [bias | alpha of the epilogue Snake][BM].  LDS is allocated in 1 280-byte granules on this chip (measured: a
+    // 54 272-byte block runs two per CU, 53 568 three): the 128 x 96 tiles (52 736 bytes) have room for exactly these two arrays.
+    static constexpr int TB_FLOATS = REG_GEOM ? 2 * BM : 0;
     static constexpr int EPI_FLOATS = CTH_FLOATS + TB_FLOATS;
     static constexpr int EPI_FLOATS_FUSE = CT_FLOATS + TB_FLOATS;
     static constexpr int LDS_FLOATS = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
@@ -337,7 +347,10 @@ struct ConvCfg {
     // spills).  Four (128 VGPRs) was measured on the 7-tap 128x128 tile: 7 dwords of scratch, +1.5 % in isolation, nothing
     // on the whole step -- not kept.
     static constexpr bool FOUR_WAVES = WAVES_M * WAVES_N == 4;
-    static constexpr int MIN_WPE = (FOUR_WAVES && LDS_FLOATS * 4 <= 53 * 1024 && !(WAVES_N == 4 && NT == 2)) ? 3
+    // Instantiations whose 3-stage ring can never be selected (> 64 KB: the register-staged loop only, with its staging
+    // registers live across the MFMAs) spilled under the 168-register cap; they take the 2-waves-per-SIMD budget.
+    static constexpr bool RING_FITS = (size_t)3 * (KC * BM + CK * XV * 4) * 4 <= 64 * 1024;
+    static constexpr int MIN_WPE = (FOUR_WAVES && LDS_FLOATS * 4 <= 53 * 1024 && !(WAVES_N == 4 && NT == 2) && RING_FITS && MT * NT <= 4) ? 3
                                                                                                                 : (WAVES_M * WAVES_N) / 2;
     static constexpr int LDS_FLOATS_FUSE = STAGE_FLOATS > EPI_FLOATS_FUSE ? STAGE_FLOATS : EPI_FLOATS_FUSE;   // fused unit: full tile
     static constexpr int MIN_WPE_FUSE = (FOUR_WAVES && (LDS_FLOATS_FUSE + 5 * BM) * 4 * 3 <= 160 * 1024) ? 3 : (WAVES_M * WAVES_N) / 2;
@@ -911,8 +924,11 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         const int g = lrow >> 5;
         return ((g / MTH) * MT + pass * MTH + (g % MTH)) * 32 + (lrow & 31);
     };
-#pragma unroll
-    for (int hp = 0; hp < EHP; ++hp) {
+    // One epilogue pass, with the pass index a compile-time constant (a generic lambda instantiated per pass: an unroll pragma on
+    // a pass LOOP is dropped once the body outgrows the unroller's size limit, and then `acc[hp * MTH + il]` is a dynamically
+    // indexed register array, i.e. scratch, and none of the regular mapping's offsets are immediates any more).
+    auto epilogue_pass = [&](auto HP) __attribute__((always_inline)) {
+    constexpr int hp = decltype(HP)::value;
     __syncthreads();                                  // every wave is done with the staging buffers / the previous pass
 #pragma unroll
     for (int il = 0; il < MTH; ++il)
@@ -933,38 +949,45 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
     constexpr bool PRE_RES = (UPS == 0) && (NVQ % C::NTHR == 0) && (NVQ / C::NTHR <= 16);
 #endif
     constexpr int RES_IT = PRE_RES ? NVQ / C::NTHR : 1;
-    // REGULAR quad mapping (every 128- / 64- / 256-column tile): NTHR is a multiple of the BN / 4 quads of a tile row, so a thread
-    // keeps ONE column quad and its rows advance by the constant RSTEP per iteration.  Everything that depends only on the column
-    // (bounds, the zero-tail / packed-gap mask) is then per-thread state, the row of iteration `it` is r0 + a compile-time
+    // REGULAR quad mapping (ConvCfg::REG_GEOM): a thread keeps its JN column quads (c4 = q_c0 + j * CQ) and its rows advance by the
+    // constant RSTEP per step, so iteration it = (row step it / JN, column group it % JN).  Everything that depends only on the
+    // column (bounds, the zero-tail / packed-gap mask) is per-thread state, the row of an iteration is q_r0 + a compile-time
     // constant (LDS reads of the tile and of the row tables take immediate offsets), and global addresses are a uniform 64-bit
     // base per block + a 32-bit per-thread offset that advances by a scalar -- the quad's vector work is the arithmetic itself.
     // (Before: e / (BN/4), the tile-row shuffle, a 64-bit address and three global loads of bias / alpha per quad; vector
-    // instructions are additive to fp32 MFMA time on this chip)
-    constexpr int QPR = C::BN / 4;
-    constexpr bool REG = PRE_RES && C::REG_GEOM;
-    constexpr int RSTEP = REG ? C::NTHR / QPR : 1;
-    const int q_c4 = REG ? tid % QPR : 0, q_r0 = REG ? tid / QPR : 0;
+    // instructions are additive to fp32 MFMA time on this chip)  The row table holds ONE Snake alpha:
+    // a launch with both a dual output and an output Snake (no layer of the model) takes the generic path.
+    constexpr int CQ = C::CQ, JN = C::JN;
+    constexpr bool REG = PRE_RES && C::REG_GEOM && (BMH % C::RSTEP == 0);
+    constexpr int RSTEP = REG ? C::RSTEP : 1;
+    const bool reg_ok = REG && !(a.y2 && a.alpha_out);
+    const int q_c0 = REG ? tid % CQ : 0, q_r0 = REG ? tid / CQ : 0;
     // row of the block tile that iteration `it` of the regular mapping handles, minus q_r0: a constant after unrolling
     auto reg_k = [&](int it, int pass) __attribute__((always_inline)) {
-        const int lr = it * RSTEP;                                     // local row (of this pass) of the thread with q_r0 == 0
+        const int lr = (it / JN) * RSTEP;                              // local row (of this pass) of the thread with q_r0 == 0
         if (EHP == 1) return lr;
         const int g = lr >> 5;
         return ((g / MTH) * MT + pass * MTH + (g % MTH)) * 32 + (lr & 31);
     };
     const size_t blk_off = ((size_t)b * a.Cout + m0) * a.Tout + n0;   // uniform: element (b, m0, n0)
-    const unsigned q_t0 = (unsigned)(q_r0 * a.Tout + 4 * q_c4);
-    const bool q_nok = n0 + 4 * q_c4 < a.Ncols;
+    const unsigned q_t0 = (unsigned)(q_r0 * a.Tout + 4 * q_c0);
+    bool q_nok[JN];
+#pragma unroll
+    for (int j = 0; j < JN; ++j) q_nok[j] = n0 + 4 * (q_c0 + j * CQ) < a.Ncols;
     f32x4 res_q[RES_IT];
     if (PRE_RES && has_res && a.ovec4) {
-        if constexpr (REG) {
+        bool pre_done = false;
+        if constexpr (REG) if (reg_ok) {
+            pre_done = true;
             const float* resb = a.residual + blk_off;
 #pragma unroll
             for (int it = 0; it < RES_IT; ++it) {
-                const int k = reg_k(it, hp);
-                const bool ok = q_nok && m0 + q_r0 + k < a.Mrows;
-                res_q[it] = *reinterpret_cast<const f32x4*>(resb + (ok ? q_t0 + (unsigned)(k * a.Tout) : 0u));
+                const int k = reg_k(it, hp), j = it % JN;
+                const bool ok = q_nok[j] && m0 + q_r0 + k < a.Mrows;
+                res_q[it] = *reinterpret_cast<const f32x4*>(resb + (ok ? q_t0 + (unsigned)(k * a.Tout) + 4u * CQ * j : 0u));
             }
-        } else {
+        }
+        if (!pre_done) {
 #pragma unroll
             for (int it = 0; it < RES_IT; ++it) {
                 const int e = tid + it * C::NTHR;
@@ -977,15 +1000,15 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             }
         }
     }
-    // epilogue row table (bias | alpha_out | alpha2 of this block's rows) behind the tile: one fill per block
+    // epilogue row table (bias | alpha of the one epilogue Snake, for this block's rows) behind the tile: one fill per block
     float* const Tb = smem + (FUSE ? C::CT_FLOATS : C::CTH_FLOATS);
-    if (UPS == 0 && REG && hp == 0) {
+    if (reg_ok && hp == 0) {
+        const float* const ax = a.y2 ? a.alpha2 : a.alpha_out;
         for (int r = tid; r < C::BM; r += C::NTHR) {
             int m = m0 + r;
             m = m < a.Mrows ? m : a.Mrows - 1;
             Tb[r] = ep_bias ? ep_bias[m] : 0.0f;
-            Tb[C::BM + r] = a.alpha_out ? a.alpha_out[m] : 1.0f;
-            Tb[2 * C::BM + r] = a.y2 ? a.alpha2[m] : 1.0f;
+            Tb[C::BM + r] = ax ? ax[m] : 1.0f;
         }
     }
     __syncthreads();
@@ -1036,27 +1059,33 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     *reinterpret_cast<f32x4*>(a.y + off) = v;
                 }
             };
-            if constexpr (REG) {
-                const int n = n0 + 4 * q_c4;
-                int nz = (a.tvalid && n + 4 > a.tvalid) ? n + 4 - a.tvalid : 0;               // trailing pad columns of this thread's quads
-                if (a.tper) {                                         // packed rows: the gap columns of every period
-                    const int nn = n - (int)__umulhi((unsigned)n, a.tper_magic) * a.tper;
-                    nz = nn + 4 > a.tper_valid ? (nn >= a.tper_valid ? 4 : nn + 4 - a.tper_valid) : 0;
+            bool quads_done = false;
+            if constexpr (REG) if (reg_ok) {
+                quads_done = true;
+                int nz[JN];                                           // trailing pad / packed-gap columns of this thread's quads
+#pragma unroll
+                for (int j = 0; j < JN; ++j) {
+                    const int n = n0 + 4 * (q_c0 + j * CQ);
+                    nz[j] = (a.tvalid && n + 4 > a.tvalid) ? n + 4 - a.tvalid : 0;
+                    if (a.tper) {                                     // packed rows: the gap columns of every period
+                        const int nn = n - (int)__umulhi((unsigned)n, a.tper_magic) * a.tper;
+                        nz[j] = nn + 4 > a.tper_valid ? (nn >= a.tper_valid ? 4 : nn + 4 - a.tper_valid) : 0;
+                    }
                 }
                 float* const yb = a.y + blk_off;
                 float* const y2b = a.y2 ? a.y2 + blk_off : nullptr;
                 const float* const dsb = a.dsn_src ? a.dsn_src + blk_off : nullptr;
-                const float* const ctq = Ct + q_r0 * C::BNP + 4 * q_c4;
+                const float* const ctq = Ct + q_r0 * C::BNP + 4 * q_c0;
                 const float* const tbq = Tb + q_r0;
                 const float* const epq = Ep + q_r0;
 #pragma unroll
                 for (int it = 0; it < RES_IT; ++it) {
-                    const int k = reg_k(it, hp);                       // compile-time after unrolling
+                    const int k = reg_k(it, hp), j = it % JN;          // compile-time after unrolling
                     const int trow = q_r0 + k;
-                    if (q_nok && m0 + trow < a.Mrows) {
-                        const unsigned toff = q_t0 + (unsigned)(k * a.Tout);
+                    if (q_nok[j] && m0 + trow < a.Mrows) {
+                        const unsigned toff = q_t0 + (unsigned)(k * a.Tout) + 4u * CQ * j;
                         const float bv = tbq[k];
-                        f32x4 v = *reinterpret_cast<const f32x4*>(ctq + it * RSTEP * C::BNP);
+                        f32x4 v = *reinterpret_cast<const f32x4*>(ctq + (it / JN) * RSTEP * C::BNP + 4 * CQ * j);
                         v.x = v.x + bv; v.y = v.y + bv; v.z = v.z + bv; v.w = v.w + bv;
                         if (a.dsn_src) {
                             const float ad = a.dsn_alpha[m0 + trow], id = epq[2 * C::BM + k];
@@ -1068,10 +1097,11 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                             const f32x4 rv = res_q[it];
                             v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
                         }
+                        const int z = nz[j];
                         if (a.y2) {
-                            const float a2 = tbq[2 * C::BM + k], i2 = epq[C::BM + k];
+                            const float a2 = tbq[C::BM + k], i2 = epq[C::BM + k];
                             f32x4 w = {det_snake(v.x, a2, i2), det_snake(v.y, a2, i2), det_snake(v.z, a2, i2), det_snake(v.w, a2, i2)};
-                            if (nz > 0) { w.w = 0.0f; if (nz > 1) w.z = 0.0f; if (nz > 2) w.y = 0.0f; if (nz > 3) w.x = 0.0f; }
+                            if (z > 0) { w.w = 0.0f; if (z > 1) w.z = 0.0f; if (z > 2) w.y = 0.0f; if (z > 3) w.x = 0.0f; }
                             *reinterpret_cast<f32x4*>(y2b + toff) = w;
                         }
                         if (snake_out) {
@@ -1081,10 +1111,12 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                         }
                         if (do_tanh) { v.x = det_tanh(v.x); v.y = det_tanh(v.y); v.z = det_tanh(v.z); v.w = det_tanh(v.w); }
                         if (do_gelu) { v.x = det_gelu(v.x); v.y = det_gelu(v.y); v.z = det_gelu(v.z); v.w = det_gelu(v.w); }
-                        if (nz > 0) { v.w = 0.0f; if (nz > 1) v.z = 0.0f; if (nz > 2) v.y = 0.0f; if (nz > 3) v.x = 0.0f; }
+                        if (z > 0) { v.w = 0.0f; if (z > 1) v.z = 0.0f; if (z > 2) v.y = 0.0f; if (z > 3) v.x = 0.0f; }
                         *reinterpret_cast<f32x4*>(yb + toff) = v;
                     }
                 }
+            }
+            if (quads_done) {
             } else if (PRE_RES) {
 #pragma unroll
                 for (int it = 0; it < RES_IT; ++it) quad(tid + it * C::NTHR, it);
@@ -1148,7 +1180,10 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             }
         }
     }
-    }   // epilogue pass
+    };   // epilogue pass
+    epilogue_pass(std::integral_constant<int, 0>{});
+    if constexpr (EHP == 2) epilogue_pass(std::integral_constant<int, 1>{});
+    static_assert(EHP == 1 || EHP == 2, "one or two epilogue passes");
 }
 
 // 16-byte input rows (Tin % 4 == 0) take the float4 staging path; the two paths are separate loop nests so that

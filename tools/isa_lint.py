@@ -11,8 +11,8 @@ Checks (every kernel of the library unless noted):
       N youngest LDS operations are done (an outstanding scalar load only makes the wait longer).  The in-flight queue is
       propagated over the kernel's control-flow graph (every distinct queue that can reach a basic block is simulated), so loops
       and the compiler's block placement are handled exactly; compiler-issued reads are judged by the same rule.
-  R3  kernels that stage by LDS-DMA (`global_load_lds_dwordx4`) use no scratch: zero `scratch_` instructions and a zero
-      private segment in the kernel descriptor metadata.
+  R3  the MFMA conv kernels (every conv1d_mfma_kernel / residual_unit_kernel instantiation, LDS-DMA or register-staged) use no
+      scratch: zero `scratch_` instructions, and a zero private segment / no VGPR spills in the metadata of the LDS-DMA ones.
   R4  every `global_load_lds_dwordx4` sits in the exact sequence
           s_mov_b32 sK, m0 / s_mov_b32 m0, sD / s_nop 0 / global_load_lds_dwordx4 ... / s_mov_b32 m0, sK
       and no other instruction of such a kernel writes M0.
@@ -310,10 +310,10 @@ def run(so: Path, kernel_filter: str | None = None, want_stats: bool = False, du
             summary["dma_kernels"] += has_dma
             summary["asm_read_kernels"] += has_asm
             violations += lint_function(name, insns)
-            if has_dma:
+            if has_dma or "conv1d_mfma_kernel" in name or "residual_unit_kernel" in name:
                 n_scr = sum(1 for _, op, _ in insns if op.startswith("scratch_"))
                 if n_scr:
-                    violations.append(f"{name}: {n_scr} scratch_ instructions in an LDS-DMA kernel (R3)")
+                    violations.append(f"{name}: {n_scr} scratch_ instructions in an MFMA conv kernel (R3)")
             if want_stats:
                 summary["stats"][name] = stats(insns)
         # R3 (metadata): private segment of the DMA kernels
