@@ -5,16 +5,6 @@ hipError_t launch_conv_k1k3(const ConvArgs& a, int ks, int bm, hipStream_t s)
 {
     if (ks == 1) {
         if (bm != 96 && conv_prefer_small_tiles(a)) return launch_conv1d_mfma<1, 1, 1, 32, 1, 1, 2, 2, 0>(a, s);
-#if defined(MVQ_TIMING_BUILD) && defined(MVQ_K1_WIDE)      // experiment: 128 x 256 tiles (wave tile 64 x 128, two blocks per CU) for the bulk of a row
-        if (bm == 128 && !a.name_out && a.n_base == 0 && a.n_tiles_max == 0 && a.Ncols >= 256 && !conv_prefer_small_tiles(a)) {
-            ConvArgs m = a, t = a;
-            m.n_tiles_max = a.Ncols / 256;
-            t.n_base = m.n_tiles_max * 256;
-            hipError_t e = launch_conv1d_mfma<1, 1, 1, 16, 2, 4, 2, 2, 0>(m, s);
-            if (e != hipSuccess || t.n_base >= a.Ncols) return e;
-            return a.Ncols - t.n_base <= 96 ? launch_conv1d_mfma<1, 1, 1, 16, 1, 3, 4, 1, 0>(t, s) : launch_conv1d_mfma<1, 1, 1, 16, 2, 2, 2, 2, 0>(t, s);
-        }
-#endif
         if (bm == 128) {
             const int tail = a.name_out ? 0 : conv_tail_width(a);
             if (tail) {                                              // full 128-column tiles, then the narrow tail tile
