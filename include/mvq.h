@@ -347,6 +347,20 @@ int mvq_conv_transpose1d_op_f32(const float* x, const float* wp, const float* bi
                                 int batch, int cin, int tin, int cout, int stride, int pad, int output_padding, int tout_rows,
                                 int tvalid, void* stream);
 
+/* VIRTUALLY PACKED latent-rate rows (round 4): the same tiling as the packed layout -- seg_per_row items side by side in one
+ * GEMM row, so a 128-column tile holds live columns only -- but with NO repacked copy of the input or the output: the LDS-DMA
+ * source of every 16-byte piece is remapped (virtual column c -> item c / per_in, position c mod per_in; positions >= tin_rows
+ * read zeros) and the epilogue stores column n to (item n / tout_rows, position n mod tout_rows) of the ordinary tensor.
+ * Used for the encoder's last strided conv (512 -> 1024, k 16, s 8, T 600 -> 75: 78 % -> 98 % live columns) and the k3 conv
+ * behind it (upstream dac Encoder tail; Training/compare_dacvsproposal_5.py:294,296).
+ *   x[batch, cin, tin_rows]: tin_valid data columns then a zero tail (caller's contract, as for the zero-padded rows below);
+ *   y[batch, cout, tout_rows]: conv_out_len(tin_valid) valid columns, the rest written as zeros.  Requirements: tin_rows,
+ *   tout_rows, per_in multiples of 4; per_in == stride * tout_rows; per_in - tin_valid >= max(pad, right overhang of the last
+ *   output); no Snake on load (the DMA cannot transform what it copies).  Same fma chains as mvq_conv1d_f32 on each item. */
+int mvq_conv1d_vpacked_f32(const float* x, const float* wp, const float* bias, const float* residual, const float* alpha_out,
+                           float* y, float* y2, const float* alpha2, int batch, int cin, int tin_rows, int tin_valid, int cout,
+                           int ks, int stride, int dil, int pad, int act, int seg_per_row, int per_in, int tout_rows, void* stream);
+
 /* PACKED latent-rate rows (round 3).  At the latent rate a segment is 75 columns wide: one 96- or 128-column tile per segment
  * leaves 22-41 % of the MFMAs on padding.  The decoder's first two layers therefore run on rows that hold `seg_per_row` segments
  * at a period of `seg_period` columns (a multiple of 4), `seg_valid` of them data and the rest ZEROS -- the zero padding each

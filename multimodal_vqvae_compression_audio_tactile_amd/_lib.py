@@ -85,6 +85,7 @@ EXPORTS = {
     "mvq_residual_unit_padded_f32": (c_int, [c_void_p] * 13 + [c_int] * 5 + [c_void_p]),
     "mvq_conv_transpose1d_padded_f32": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_void_p]),
     "mvq_conv1d_packed_rows_f32": (c_int, [c_void_p] * 8 + [c_int] * 10 + [c_void_p]),
+    "mvq_conv1d_vpacked_f32": (c_int, [c_void_p] * 8 + [c_int] * 13 + [c_void_p]),
     "mvq_conv_transpose1d_packed_rows_f32": (c_int, [c_void_p] * 8 + [c_int] * 9 + [c_void_p]),
     "mvq_conv_transpose1d_op_f32": (c_int, [c_void_p] * 8 + [c_int] * 9 + [c_void_p]),
     "mvq_layernorm_c_sub_f32": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_size_t] * 2 + [c_float, c_int, c_float, c_void_p]),

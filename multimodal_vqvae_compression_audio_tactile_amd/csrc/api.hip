@@ -337,6 +337,42 @@ int mvq_conv1d_packed_rows_f32(const float* x, const float* wp, const float* bia
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_packed_rows");
 }
 
+int mvq_conv1d_vpacked_f32(const float* x, const float* wp, const float* bias, const float* residual, const float* alpha_out,
+                           float* y, float* y2, const float* alpha2, int batch, int cin, int tin_rows, int tin_valid, int cout,
+                           int ks, int stride, int dil, int pad, int act, int seg_per_row, int per_in, int tout_rows, void* stream)
+{
+    if (batch < 0 || cin <= 0 || cout <= 0 || ks <= 0 || stride <= 0 || dil <= 0 || pad < 0 || tin_rows <= 0 || tin_valid < 0 ||
+        tin_valid > tin_rows || seg_per_row <= 0 || per_in <= 0 || tout_rows <= 0)
+        return fail(MVQ_EINVAL, "conv1d_vpacked: bad shape");
+    if (act != MVQ_ACT_NONE && act != MVQ_ACT_TANH && act != MVQ_ACT_GELU) return fail(MVQ_EINVAL, "conv1d_vpacked: bad act %d", act);
+    const int tout = conv_out_len(tin_valid, ks, stride, dil, pad);             /* valid outputs per item */
+    /* geometry of the virtual row: the output period is the physical output row, the input period is stride x that; between the
+     * data of neighbouring items there must be at least `pad` zeros on the left and the last valid output's overhang on the right
+     * (columns [tin_valid, tin_rows) of x are the caller's zero tail, columns beyond tin_rows come from the zero block) */
+    const int per_out = tout_rows;
+    const int overhang = (tout > 0 ? (tout - 1) * stride - pad + dil * (ks - 1) : 0) - (tin_valid - 1);   /* zeros needed behind the data */
+    if (tin_rows % 4 != 0 || tout_rows % 4 != 0 || per_in % 4 != 0 || per_in != stride * per_out || tout > tout_rows ||
+        tin_rows > per_in || per_in - tin_valid < pad || per_in - tin_valid < overhang)
+        return fail(MVQ_EINVAL, "conv1d_vpacked: needs 16-byte rows, per_in == stride * tout_rows, tout <= tout_rows and a gap of at least "
+                                "max(pad, overhang) zeros between items (tin_rows %d valid %d per_in %d tout %d tout_rows %d pad %d overhang %d)",
+                    tin_rows, tin_valid, per_in, tout, tout_rows, pad, overhang);
+    if ((long long)seg_per_row * per_in * per_in >= ((long long)1 << 32)) return fail(MVQ_EINVAL, "conv1d_vpacked: virtual row too long");
+    if (batch == 0 || tout == 0) return MVQ_OK;
+    if (!x || !wp || !y) return fail(MVQ_EINVAL, "conv1d_vpacked: null tensor");
+    if ((y2 != nullptr) != (alpha2 != nullptr)) return fail(MVQ_EINVAL, "conv1d_vpacked: y2 and alpha2 go together");
+    if (y2 && alpha_out) return fail(MVQ_EUNSUPPORTED, "conv1d_vpacked: a dual output and an output Snake together are not supported");
+    mvq::ConvArgs a{};
+    a.x = x; a.wp = wp; a.bias = bias; a.residual = residual; a.alpha_out = alpha_out; a.y = y; a.y2 = y2; a.alpha2 = alpha2;
+    a.B = (batch + seg_per_row - 1) / seg_per_row;                               /* virtual rows */
+    a.Cin = cin; a.Tin = seg_per_row * per_in; a.Cout = cout; a.Tout = tout_rows; a.pad = pad; a.Mpad = mvq::conv_mpad(cout);
+    a.Mrows = cout; a.Ncols = seg_per_row * per_out; a.act = act; a.up_s = 1;
+    a.vp_seg = seg_per_row; a.vp_per_in = per_in; a.vp_valid_in = tin_rows; a.vp_tin_phys = tin_rows; a.vp_btrue = batch;
+    a.vp_per_out = per_out; a.vp_valid_out = tout; a.vp_magic_in = magic_div(per_in); a.vp_magic_out = magic_div(per_out);
+    hipError_t e = dispatch_conv1d(a, ks, stride, dil, S(stream));
+    if (e == hipErrorInvalidValue) return fail(MVQ_EUNSUPPORTED, "conv1d_vpacked: needs an MFMA-tiled, LDS-DMA-staged shape with the regular epilogue");
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_vpacked");
+}
+
 int mvq_conv_transpose1d_packed_rows_f32(const float* x, const float* wp, const float* bias, const float* alpha_in,
                                          const float* alpha_out, float* y, float* y2, const float* alpha2, int rows, int cin,
                                          int cout, int stride, int pad, int seg_per_row, int seg_period, int seg_valid,

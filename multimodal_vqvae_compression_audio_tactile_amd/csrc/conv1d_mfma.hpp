@@ -90,6 +90,14 @@ struct ConvArgs {
     unsigned tper_magic;
     int up_per_out, up_valid_out, up_seg, up_btrue;
     unsigned up_magic;
+    // VIRTUALLY PACKED rows (latent-rate layers, include/mvq.h mvq_conv1d_vpacked_f32): the GEMM's B matrix is a VIRTUAL row that
+    // holds vp_seg segments at a period of vp_per_in columns, but neither the input nor the output is repacked in memory -- the
+    // LDS-DMA source of every 16-byte piece is remapped (virtual column c -> item b * vp_seg + c / vp_per_in, position
+    // c mod vp_per_in; positions >= vp_valid_in and items >= vp_btrue read the zero block) and the epilogue maps an output column
+    // n -> item b * vp_seg + n / vp_per_out, position n mod vp_per_out of the ordinary [vp_btrue, Cout, Tout] tensor (Tout =
+    // the physical row length, positions >= vp_valid_out written as zeros).  LDS-DMA staging + regular epilogue only.
+    int vp_seg, vp_per_in, vp_valid_in, vp_tin_phys, vp_btrue, vp_per_out, vp_valid_out;
+    unsigned vp_magic_in, vp_magic_out;
     char* name_out;         // host only: when set, launchers write the kernel instantiation name here and do not launch
     int name_len;
 };
@@ -656,9 +664,19 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 const int q = (p < C::DMA_NV ? p : C::DMA_NV - 1) - C::W_VEC;
                 const int cl = q / C::XV, v = q - cl * C::XV;
                 const int g = g_al + 4 * v;
-                const bool ok = g >= 0 && g < a.Tin;
-                src[u] = ok ? tile.xb + (size_t)cl * a.Tin + g : g_zero16;
-                step_b[u] = ok ? (long long)CK * a.Tin : 0;
+                bool ok = g >= 0 && g < a.Tin;
+                const float* sp = tile.xb + (size_t)cl * a.Tin + g;
+                long long st = (long long)CK * a.Tin;
+                if (a.vp_seg) {                                        // virtually packed row: remap the piece to its item / position
+                    const int gg = ok ? g : 0;
+                    const int seg = (int)__umulhi((unsigned)gg, a.vp_magic_in), pos = gg - seg * a.vp_per_in;
+                    const int item = b * a.vp_seg + seg;
+                    ok = ok && pos < a.vp_valid_in && item < a.vp_btrue;
+                    sp = a.x + ((size_t)(ok ? item : 0) * a.Cin + cl) * a.vp_tin_phys + (ok ? pos : 0);
+                    st = (long long)CK * a.vp_tin_phys;
+                }
+                src[u] = ok ? sp : g_zero16;
+                step_b[u] = ok ? st : 0;
             }
         }
         const unsigned lds0 = (unsigned)(size_t)smem;                    // LDS byte address of the ring
@@ -969,11 +987,27 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         const int g = lr >> 5;
         return ((g / MTH) * MT + pass * MTH + (g % MTH)) * 32 + (lr & 31);
     };
-    const size_t blk_off = ((size_t)b * a.Cout + m0) * a.Tout + n0;   // uniform: element (b, m0, n0)
-    const unsigned q_t0 = (unsigned)(q_r0 * a.Tout + 4 * q_c0);
+    // uniform base: element (b, m0, n0) -- or, for virtually packed rows, row m0 of the block's first item (the column part of
+    // the address then comes from the per-thread (item, position) of each column quad)
+    const size_t blk_off = a.vp_seg ? ((size_t)b * a.vp_seg * a.Cout + m0) * a.Tout : ((size_t)b * a.Cout + m0) * a.Tout + n0;
+    const unsigned q_t0 = (unsigned)(q_r0 * a.Tout);
     bool q_nok[JN];
+    unsigned q_col[JN];                                               // column part of this thread's offsets, per column group
+    int q_vpos[JN];                                                   // virtually packed: position inside the item's row
 #pragma unroll
-    for (int j = 0; j < JN; ++j) q_nok[j] = n0 + 4 * (q_c0 + j * CQ) < a.Ncols;
+    for (int j = 0; j < JN; ++j) {
+        const int n = n0 + 4 * (q_c0 + j * CQ);
+        q_nok[j] = n < a.Ncols;
+        q_col[j] = 4u * (q_c0 + j * CQ);
+        q_vpos[j] = 0;
+        if (a.vp_seg) {
+            const int nn = q_nok[j] ? n : 0;
+            const int seg = (int)__umulhi((unsigned)nn, a.vp_magic_out), pos = nn - seg * a.vp_per_out;
+            q_nok[j] = q_nok[j] && b * a.vp_seg + seg < a.vp_btrue && pos < a.Tout;
+            q_col[j] = (unsigned)(seg * a.Cout * a.Tout + pos);
+            q_vpos[j] = pos;
+        }
+    }
     f32x4 res_q[RES_IT];
     if (PRE_RES && has_res && a.ovec4) {
         bool pre_done = false;
@@ -984,7 +1018,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
             for (int it = 0; it < RES_IT; ++it) {
                 const int k = reg_k(it, hp), j = it % JN;
                 const bool ok = q_nok[j] && m0 + q_r0 + k < a.Mrows;
-                res_q[it] = *reinterpret_cast<const f32x4*>(resb + (ok ? q_t0 + (unsigned)(k * a.Tout) + 4u * CQ * j : 0u));
+                res_q[it] = *reinterpret_cast<const f32x4*>(resb + (ok ? q_t0 + (unsigned)(k * a.Tout) + q_col[j] : 0u));
             }
         }
         if (!pre_done) {
@@ -1071,6 +1105,10 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                         const int nn = n - (int)__umulhi((unsigned)n, a.tper_magic) * a.tper;
                         nz[j] = nn + 4 > a.tper_valid ? (nn >= a.tper_valid ? 4 : nn + 4 - a.tper_valid) : 0;
                     }
+                    if (a.vp_seg) {                                   // virtually packed rows: the zero tail of the item's own row
+                        const int pp = q_vpos[j];
+                        nz[j] = pp + 4 > a.vp_valid_out ? (pp >= a.vp_valid_out ? 4 : pp + 4 - a.vp_valid_out) : 0;
+                    }
                 }
                 float* const yb = a.y + blk_off;
                 float* const y2b = a.y2 ? a.y2 + blk_off : nullptr;
@@ -1083,7 +1121,7 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                     const int k = reg_k(it, hp), j = it % JN;          // compile-time after unrolling
                     const int trow = q_r0 + k;
                     if (q_nok[j] && m0 + trow < a.Mrows) {
-                        const unsigned toff = q_t0 + (unsigned)(k * a.Tout) + 4u * CQ * j;
+                        const unsigned toff = q_t0 + (unsigned)(k * a.Tout) + q_col[j];
                         const float bv = tbq[k];
                         f32x4 v = *reinterpret_cast<const f32x4*>(ctq + (it / JN) * RSTEP * C::BNP + 4 * CQ * j);
                         v.x = v.x + bv; v.y = v.y + bv; v.z = v.z + bv; v.w = v.w + bv;
@@ -1273,6 +1311,11 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
         if (e != hipSuccess) return e;
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (a.vp_seg) {   // virtually packed rows exist in the LDS-DMA loop and the regular 16-byte epilogue only
+        constexpr int EHP_ = C::EH, NVQ_ = (C::BM / EHP_) * C::BN / 4;
+        constexpr bool REG_ = C::REG_GEOM && (NVQ_ % C::NTHR == 0) && (NVQ_ / C::NTHR <= 16) && ((C::BM / EHP_) % C::RSTEP == 0);
+        if (!REG_ || UPS != 0 || !a.dma || !a.ovec4 || (a.y2 && a.alpha_out)) return hipErrorInvalidValue;
+    }
     const unsigned gx = (unsigned)(a.n_tiles * a.B), R = (unsigned)((a.Mrows + C::BM - 1) / C::BM);
     dim3 grid(gx, R);
     // Row tiles share the input tile, column tiles share the weight rows.  Default order (row tile slowest) keeps ONE
@@ -1303,6 +1346,7 @@ inline hipError_t launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t stream)
         double cols = last > a.n_base ? last - a.n_base : 0;
         // packed rows: only the data columns of every period count
         if (a.tper) cols *= (double)a.tper_valid / a.tper;
+        if (a.vp_seg) cols *= ((double)a.vp_valid_out / a.vp_per_out) * ((double)a.vp_btrue / ((double)a.B * a.vp_seg));
         if (a.up_per_out) cols *= (double)a.up_valid_out / a.up_per_out;
         pi = prof_begin(nm, 2.0 * a.Cin * KS * a.Mrows * cols * a.B, stream);
     }
@@ -1349,6 +1393,7 @@ inline int conv_tail_width(const ConvArgs& a)
 inline bool conv_prefer_small_tiles(const ConvArgs& a)
 {
     if (a.Mpad % 64 != 0) return false;
+    if (a.vp_seg) return false;                       // virtually packed rows: the LDS-DMA 128-row tiles only
     const long big = (long)a.B * ((a.Ncols + 127) / 128) * ((a.Mrows + 127) / 128);
     return big < 160;
 }

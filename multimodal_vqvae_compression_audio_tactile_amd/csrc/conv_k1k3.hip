@@ -30,7 +30,9 @@ hipError_t launch_conv_k1k3(const ConvArgs& a, int ks, int bm, hipStream_t s)
         if (bm != 96 && conv_prefer_small_tiles(a)) return launch_conv1d_mfma<3, 1, 1, 16, 1, 1, 2, 2, 0>(a, s);
         if (bm == 128 && a.Ncols <= 96) return launch_conv1d_mfma<3, 1, 1, 8, 1, 3, 4, 1, 0>(a, s);
         switch (bm) {
-            case 128: return launch_conv1d_mfma<3, 1, 1, 16, 2, 2, 2, 2, 0>(a, s);
+            // 8-channel stages keep the 3-stage LDS-DMA ring at 50 KB (16-channel stages: 101 KB, register-staged loop only)
+            case 128: return conv_dma_rows_ok(a) ? launch_conv1d_mfma<3, 1, 1, 8, 2, 2, 2, 2, 0>(a, s)
+                                                 : launch_conv1d_mfma<3, 1, 1, 16, 2, 2, 2, 2, 0>(a, s);
         }
     }
     return hipErrorInvalidValue;

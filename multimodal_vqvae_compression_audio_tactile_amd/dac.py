@@ -111,6 +111,11 @@ class WNConv1d(_WNKeys, nn.Module):
                           dil=self.dilation, pad=self.padding, alpha_in=alpha_in, residual=residual,
                           alpha_out=alpha_out, tanh=tanh, alpha_dual=alpha_dual, tvalid=tvalid)
 
+    def run_vpacked(self, x, seg_per_row, tin_valid, tout_rows, alpha_out=None):
+        """The same conv on virtually packed rows (ops.conv1d_vpacked): x[B, cin, rows] with tin_valid data columns."""
+        return ops.conv1d_vpacked(x, self.packed(), self.cout, self.ks, seg_per_row, tin_valid, tout_rows, bias=self.bias.detach(),
+                                  stride=self.stride, dil=self.dilation, pad=self.padding, alpha_out=alpha_out)
+
     def forward(self, x):
         return self.run(x)
 
@@ -193,7 +198,9 @@ class EncoderBlock(nn.Module):
                                    Snake1d(dim // 2),
                                    WNConv1d(dim // 2, dim, 2 * stride, stride=stride, padding=math.ceil(stride / 2)))
 
-    def run(self, x, alpha_next=None, x_snaked=None, alpha_dual=None):
+    def run(self, x, alpha_next=None, x_snaked=None, alpha_dual=None, vpack=None):
+        """vpack = (seg_per_row, follow_pad): run the strided conv on virtually packed rows and return (y_rows, valid length);
+        falls back to the plain launch (y, None) when the shape does not qualify."""
         r0, r1, r2 = self.block[0], self.block[1], self.block[2]
         wide = r0.wants_presnaked()
         if wide:
@@ -204,7 +211,14 @@ class EncoderBlock(nn.Module):
             x = r0.run(x)
             x = r1.run(x)
             x = r2.run(x, alpha_next=self.block[3].flat())            # Snake before the strided conv, fused
-        return self.block[4].run(x, alpha_out=alpha_next, alpha_dual=alpha_dual)
+        down = self.block[4]
+        if vpack is not None:
+            geo = ops.vpacked_geometry(x.shape[-1], x.shape[-1], down.ks, down.stride, down.dilation, down.padding, follow_pad=vpack[1])
+            if geo is not None and alpha_dual is None and down.cin % 32 == 0 and down.cout % 128 == 0:
+                tout, tout_rows, _ = geo
+                return down.run_vpacked(x, vpack[0], x.shape[-1], tout_rows, alpha_out=alpha_next), tout
+            return down.run(x, alpha_out=alpha_next, alpha_dual=alpha_dual), None
+        return down.run(x, alpha_out=alpha_next, alpha_dual=alpha_dual)
 
     def first_alpha(self):
         """alpha of the first ResidualUnit's input Snake if that unit wants it pre-applied by the producer."""
@@ -233,12 +247,38 @@ class Encoder(nn.Module):
         a1 = self.block[1].first_alpha()                            # first unit wants a pre-snaked input: dual output of the 1 -> 64 conv
         out = self.block[0].run(x, alpha_dual=a1)
         h, hs = out if a1 is not None else (out, None)
+        tail = self.block[n - 1]                                     # the k3 conv behind the trailing Snake
+        vpack = self._vpack(x.shape[0], tail)
+        tv = None
         for i in range(1, n - 2):
             last = i == n - 3
             nxt = None if last else self.block[i + 1].first_alpha()   # next block's first unit wants a pre-snaked input?
+            if last and vpack is not None:
+                h, tv = self.block[i].run(h, alpha_next=self.block[n - 2].flat(), x_snaked=hs, vpack=vpack)
+                hs = None
+                continue
             out = self.block[i].run(h, alpha_next=self.block[n - 2].flat() if last else None, x_snaked=hs, alpha_dual=nxt)
             h, hs = out if nxt is not None else (out, None)
-        return self.block[n - 1].run(h)
+        if tv is not None:
+            # latent-rate layers on virtually packed rows: h[B, C, rows] carries tv valid columns + a zero tail; the k3 conv maps
+            # rows -> rows (its padding is that zero tail), then the tail is cut off
+            y = tail.run_vpacked(h, vpack[0], tv, h.shape[-1])
+            return y[..., :tv].contiguous()
+        return tail.run(h)
+
+    # Throughput batches: the last strided conv (T 600 -> 75) and the k3 conv run on VIRTUALLY packed rows (include/mvq.h):
+    # VPACK_SEG items side by side in one GEMM row -- 10 x 76 = 760 columns = six 128-column tiles, 98 % live (unpacked: one
+    # 128 x 96 tile per item, 78 % live) -- with no repacked copy in memory.  MVQ_VPACKED_LATENTS=0 switches it off (A/B runs).
+    VPACK_SEG = 10
+    VPACK_MIN_BATCH = 32
+    VPACKED = os.environ.get("MVQ_VPACKED_LATENTS", "1") != "0"
+
+    def _vpack(self, batch, tail):
+        if not self.VPACKED or batch < self.VPACK_MIN_BATCH:
+            return None
+        if tail.stride != 1 or tail.dilation != 1 or 2 * tail.padding != tail.ks - 1 or tail.cin % 32 or tail.cout % 128:
+            return None
+        return (self.VPACK_SEG, tail.padding)
 
 
 class DecoderBlock(nn.Module):

@@ -209,6 +209,36 @@ def conv1d_packed_rows(xp, wp, cout, ks, seg_per_row, seg_period, seg_valid, bia
     return out if alpha_dual is None else (out, y2)
 
 
+def vpacked_geometry(tin_rows, tin_valid, ks, stride, dil, pad, follow_pad=0):
+    """(tout, tout_rows, per_in) of mvq_conv1d_vpacked_f32 for a conv over x[..., tin_rows] with tin_valid data columns, or None
+    when the shape does not qualify.  tout_rows leaves `follow_pad` zero columns behind the valid outputs (the padding the NEXT
+    conv needs when it runs on these rows virtually packed too)."""
+    tout = conv1d_out_len(tin_valid, ks, stride, dil, pad)
+    if tin_rows % 4 or tout <= 0:
+        return None
+    overhang = (tout - 1) * stride - pad + dil * (ks - 1) - (tin_valid - 1)
+    gap = max(pad, overhang, 0)
+    tout_rows = (max(tout + follow_pad, -(-(tin_valid + gap) // stride), -(-tin_rows // stride)) + 3) // 4 * 4
+    return tout, tout_rows, stride * tout_rows
+
+
+def conv1d_vpacked(x, wp, cout, ks, seg_per_row, tin_valid, tout_rows, bias=None, stride=1, dil=1, pad=0, residual=None,
+                   alpha_out=None, alpha_dual=None, tanh=False):
+    """Conv over VIRTUALLY packed rows (include/mvq.h): x[B, cin, tin_rows] with tin_valid data columns + zero tail ->
+    y[B, cout, tout_rows] (valid outputs, then zeros).  No copy is made: the kernel's LDS-DMA sources and its stores are remapped."""
+    x = _dev(x, "x")
+    B, cin, tin_rows = x.shape
+    per_in = stride * tout_rows
+    out = torch.empty(B, cout, tout_rows, device=x.device, dtype=torch.float32)
+    y2 = torch.empty_like(out) if alpha_dual is not None else None
+    if residual is not None and tuple(residual.shape) != tuple(out.shape):
+        raise MvqError(f"conv1d_vpacked: residual shape {tuple(residual.shape)} != {tuple(out.shape)}")
+    check(_lib.lib().mvq_conv1d_vpacked_f32(x.data_ptr(), wp.data_ptr(), _p(bias), _p(residual), _p(alpha_out), out.data_ptr(),
+                                            _p(y2), _p(alpha_dual), B, cin, tin_rows, int(tin_valid), cout, ks, stride, dil, pad,
+                                            1 if tanh else 0, int(seg_per_row), per_in, tout_rows, _stream()), "mvq_conv1d_vpacked_f32")
+    return out if alpha_dual is None else (out, y2)
+
+
 def conv_transpose1d_packed_rows(xp, wp, cout, stride, pad, seg_per_row, seg_period, seg_valid, batch_out, bias=None,
                                  alpha_in=None, alpha_out=None, alpha_dual=None):
     """ConvTranspose1d(kernel 2*stride, stride, pad) reading PACKED rows, writing the unpacked y[batch_out, cout, Tseg]."""

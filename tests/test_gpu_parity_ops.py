@@ -451,3 +451,54 @@ print(hashlib.sha256(b"".join(o.cpu().numpy().tobytes() for o in outs)).hexdiges
         assert res.returncode == 0, res.stderr[-2000:]
         digests.append(res.stdout.strip().splitlines()[-1])
     assert digests[0] == digests[1]
+
+
+def test_conv1d_vpacked_equals_the_plain_conv(dev):
+    """Virtually packed latent-rate rows (mvq_conv1d_vpacked_f32): the encoder's last strided conv (k 16, s 8, T 600 -> 75) and the
+    k3 conv behind it, 10 items per GEMM row with remapped LDS-DMA sources / stores and no repacked copy, against the plain
+    launches -- bit-equal on every valid column, zeros in the tail, ragged last row (batch not a multiple of 10) included."""
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    g = torch.Generator().manual_seed(21)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    for B in (37, 10, 3):
+        x = r(B, 512, 600)
+        w = r(1024, 512, 16) / 90.0
+        wp = ops.pack_conv1d(w)
+        bias, al = r(1024), (torch.rand(1024, generator=g) + 0.5).to(dev)
+        want = ops.conv1d(x, wp, 1024, 16, bias=bias, stride=8, pad=4, alpha_out=al)            # [B, 1024, 75]
+        tout, rows, per_in = ops.vpacked_geometry(600, 600, 16, 8, 1, 4, follow_pad=1)
+        assert (tout, rows, per_in) == (75, 76, 608)
+        got = ops.conv1d_vpacked(x, wp, 1024, 16, 10, 600, rows, bias=bias, stride=8, pad=4, alpha_out=al)
+        assert got.shape == (B, 1024, 76)
+        assert torch.equal(got[..., :75], want) and not got[..., 75:].any()
+        # the k3 conv on those rows (its padding = the zero tail of each item's row)
+        w3 = r(1024, 1024, 3) / 55.0
+        wp3 = ops.pack_conv1d(w3)
+        b3 = r(1024)
+        want3 = ops.conv1d(want, wp3, 1024, 3, bias=b3, pad=1)
+        got3 = ops.conv1d_vpacked(got, wp3, 1024, 3, 10, 75, 76, bias=b3, pad=1)
+        assert torch.equal(got3[..., :75], want3) and not got3[..., 75:].any()
+    # shapes that do not qualify are refused, not mis-computed
+    from multimodal_vqvae_compression_audio_tactile_amd._lib import MvqError
+    with pytest.raises(MvqError):
+        ops.conv1d_vpacked(r(4, 512, 602), wp, 1024, 16, 10, 602, 76, bias=bias, stride=8, pad=4)      # rows that are not 16-byte multiples
+    with pytest.raises(MvqError):
+        ops.conv1d_vpacked(r(4, 512, 600), wp, 1024, 16, 10, 600, 72, bias=bias, stride=8, pad=4)      # period too short for the outputs
+
+
+def test_encoder_virtually_packed_tail_is_bit_equal(dev):
+    """Encoder.forward with the latent-rate tail on virtually packed rows (batches >= 32) == the unpacked launch plan."""
+    from multimodal_vqvae_compression_audio_tactile_amd import Encoder, synth
+    enc = Encoder(); enc.load_state_dict(synth.encoder_state(5), strict=True); enc = enc.to(dev)
+    x = synth.tactile_segments(37, seed=3).to(dev)
+    assert Encoder.VPACKED
+    y = enc(x)
+    try:
+        Encoder.VPACKED = False
+        y0 = enc(x)
+    finally:
+        Encoder.VPACKED = True
+    assert y.shape == y0.shape == (37, 1024, 75) and torch.equal(y, y0)
+    # a length whose latent rows do not qualify falls back silently to the plain plan
+    x2 = synth.tactile_segments(33, seed=4, T=24000 - 320 * 3 + 16).to(dev)
+    assert enc(x2).shape[0] == 33
