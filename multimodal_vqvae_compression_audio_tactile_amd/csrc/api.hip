@@ -163,6 +163,7 @@ unsigned mvq_build_flags(void)
     if (getenv("MVQ_NO_DMA")) mvq::note_env_override(MVQ_BF_ENV_NO_DMA);
     if (getenv("MVQ_ROWFAST_MAX_KB")) mvq::note_env_override(MVQ_BF_ENV_ROWFAST);
     if (getenv("MVQ_NO_TOKEN_RVQ")) mvq::note_env_override(MVQ_BF_ENV_NO_TOKEN_RVQ);
+    if (getenv("MVQ_LN_TILE32")) mvq::note_env_override(0x800);
     return mvq::conv_compile_flags() | __atomic_load_n(&mvq::g_env_flags, __ATOMIC_RELAXED);
 }
 const char* mvq_last_error(void) { return g_err; }

@@ -3,6 +3,7 @@
 //   stacks (Cin = 1, Cout = 1, odd shapes), LayerNorm / attention / GELU of the CrossPredictor and row
 //   glue.  All follow the arithmetic contract of include/mvq.h (sequential fp32 fma chains).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "det_math.hpp"
 #include "kernels_small.hpp"
 
@@ -493,11 +494,20 @@ hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamm
     if (n == 0) return hipSuccess;
     const size_t lds = ((size_t)C * 32 + 2 * 32) * sizeof(float);
     if (lds <= 160 * 1024) {
-        static BigLdsOptIn opt32, opt4;
+        static BigLdsOptIn opt32, opt8, opt4;
         hipError_t e = opt32.ensure(reinterpret_cast<const void*>(layernorm_c_tile_kernel<32>));
+        if (e == hipSuccess) e = opt8.ensure(reinterpret_cast<const void*>(layernorm_c_tile_kernel<8>));
         if (e == hipSuccess) e = opt4.ensure(reinterpret_cast<const void*>(layernorm_c_tile_kernel<4>));
         if (e != hipSuccess) return e;
-        if (n <= 64)
+        // The per-token chain (2 x C dependent operations) is latency, not bandwidth: what shortens a call is MORE BLOCKS walking
+        // chains side by side.  8-token tiles (32 KB of LDS at C = 1024: five blocks per CU) put 2 400 blocks on the 19 200 tokens
+        // of a 256-segment batch where the 32-token tile (128 KB, one block per CU) put 600 -- round 4: 2.3 -> see DESIGN 6c ms per step.
+        static const bool ln32 = getenv("MVQ_LN_TILE32") != nullptr;       // A/B knob (reported by mvq_build_flags)
+        if (ln32) note_env_override(0x800);
+        if (n > 64 && !ln32 && ((size_t)C * 8 + 16) * sizeof(float) <= 64 * 1024)
+            hipLaunchKernelGGL(layernorm_c_tile_kernel<8>, dim3((n + 7) / 8), dim3(256), ((size_t)C * 8 + 16) * sizeof(float), s,
+                               x, pe, gamma, beta, y, B, C, T, sb, sc, eps, do_tanh, post_scale, sub);
+        else if (n <= 64)
             hipLaunchKernelGGL(layernorm_c_tile_kernel<4>, dim3((n + 3) / 4), dim3(256), ((size_t)C * 4 + 8) * sizeof(float), s,
                                x, pe, gamma, beta, y, B, C, T, sb, sc, eps, do_tanh, post_scale, sub);
         else

@@ -218,9 +218,13 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_kernel(
 // ------------------------------------------------------------------------------------------------
 typedef float rvq_f32x16 __attribute__((ext_vector_type(16)));
 
+// Round 4: (1) `tpb` live tokens per block (16 when 32 would leave half of the 256 CUs without a block: an AR chunk of 256 segments
+// is 4 096 tokens = 128 blocks of 32), the tile keeps its 32 MFMA columns and the dead ones are masked; (2) the 0.5 |e|^2 chain and
+// the MFMA operand fetch issue their LDS reads a batch ahead of the dependent arithmetic (both were one exposed LDS latency per
+// element / per k-step).  Same chains, same order: indices and sums bit-identical (tests/test_gpu_parity_ops.py).
 __global__ __launch_bounds__(256) void rvq_ema_forward_mfma_kernel(
     const float* __restrict__ z, const float* __restrict__ books, float* __restrict__ q_out,
-    int32_t* __restrict__ idx_out, int B, int D, int T, int nb, int K, int update_residual)
+    int32_t* __restrict__ idx_out, int B, int D, int T, int nb, int K, int update_residual, int tpb)
 {
     constexpr int TOKS = 32;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -237,13 +241,14 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int N = B * T;
-    const int n0 = blockIdx.x * TOKS;
+    const int n0 = blockIdx.x * tpb;
+    const int n_end = n0 + tpb < N ? n0 + tpb : N;                    // tokens [n0, n_end) belong to this block
 
     for (int i = tid; i < D * TOKS; i += 256) {
         const int tok = i % TOKS, d = i / TOKS;
         const int n = n0 + tok;
         float v = 0.0f;
-        if (n < N) { const int b = n / T, t = n - b * T; v = z[((size_t)b * D + d) * T + t]; }
+        if (n < n_end) { const int b = n / T, t = n - b * T; v = z[((size_t)b * D + d) * T + t]; }
         resT[d * TOKS + tok] = v;
         qsT[d * TOKS + tok] = 0.0f;
     }
@@ -284,7 +289,16 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_mfma_kernel(
             __syncthreads();
             for (int k = tid; k < kh; k += 256) {
                 float s = 0.0f;
-                for (int d = 0; d < D; ++d) { const float e = Es[(size_t)k * DP + d]; s = dfma(e, e, s); }
+                const float* er = Es + (size_t)k * DP;
+                int d = 0;
+                for (; d + 16 <= D; d += 16) {                            // 16 reads in flight, then the ordered chain
+                    float e[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) e[u] = er[d + u];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) s = dfma(e[u], e[u], s);
+                }
+                for (; d < D; ++d) { const float e = er[d]; s = dfma(e, e, s); }
                 hn[k] = 0.5f * s;
             }
             __syncthreads();
@@ -300,7 +314,20 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_mfma_kernel(
                 const float* ap0 = Es + (size_t)(mb * 32 + l31) * DP + h;
                 const float* ap1 = Es + (size_t)((two ? mb + 4 : mb) * 32 + l31) * DP + h;
                 const float* bp = resT + h * TOKS + l31;
-                for (int sx = 0; sx < D / 2; ++sx) {                         // K index = dimension, two per step
+                // K index = dimension, two per step; operands of 4 steps (12 LDS reads) are fetched ahead of their 8 MFMAs
+                const int steps = D / 2;
+                int sx = 0;
+                for (; sx + 4 <= steps; sx += 4) {
+                    float bq[4], a0[4], a1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { bq[u] = bp[2 * (sx + u) * TOKS]; a0[u] = ap0[2 * (sx + u)]; a1[u] = ap1[2 * (sx + u)]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], bq[u], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], bq[u], acc1, 0, 0, 0);
+                    }
+                }
+                for (; sx < steps; ++sx) {
                     const float b = bp[2 * sx * TOKS];
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap0[2 * sx], b, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap1[2 * sx], b, acc1, 0, 0, 0);
@@ -346,7 +373,7 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_mfma_kernel(
             qsT[d * TOKS + tok] = (qs + (q - r)) + r;
             if (update_residual) resT[d * TOKS + tok] = r - q;
         }
-        if (idx_out && tid < TOKS && n0 + tid < N) {
+        if (idx_out && tid < TOKS && n0 + tid < n_end) {
             int id = best_i[tid];
             if (id < 0 || id >= K) id = 0;
             idx_out[(size_t)bk * N + n0 + tid] = id;
@@ -357,7 +384,7 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_mfma_kernel(
         for (int i = tid; i < D * TOKS; i += 256) {
             const int tok = i % TOKS, d = i / TOKS;
             const int n = n0 + tok;
-            if (n < N) { const int b = n / T, t = n - b * T; q_out[((size_t)b * D + d) * T + t] = qsT[d * TOKS + tok]; }
+            if (n < n_end) { const int b = n / T, t = n - b * T; q_out[((size_t)b * D + d) * T + t] = qsT[d * TOKS + tok]; }
         }
     }
 }
@@ -369,8 +396,9 @@ static hipError_t launch_rvq_mfma(const float* z, const float* books, float* q_o
     const size_t lds = ((size_t)RVQ_KH * (D + 1) + RVQ_KH + 2 * (size_t)D * 32 + 8 * 32 + 2 * 32) * sizeof(float);
     static BigLdsOptIn opt;
     if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(rvq_ema_forward_mfma_kernel)); e != hipSuccess) return e;
-    hipLaunchKernelGGL(rvq_ema_forward_mfma_kernel, dim3((N + 31) / 32), dim3(256), lds, s, z, books, q_out, idx_out, B, D, T,
-                       nb, K, update_residual);
+    const int tpb = (N + 31) / 32 < 256 ? 16 : 32;        // every CU gets a block before any block gets 32 tokens
+    hipLaunchKernelGGL(rvq_ema_forward_mfma_kernel, dim3((N + tpb - 1) / tpb), dim3(256), lds, s, z, books, q_out, idx_out, B, D, T,
+                       nb, K, update_residual, tpb);
     return hipGetLastError();
 }
 
