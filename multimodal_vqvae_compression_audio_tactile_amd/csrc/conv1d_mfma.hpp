@@ -1193,6 +1193,88 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         const int nco = BMH / S;
         const int t_base = n0 * S - a.up_p;
         const int total = nco * run;
+        // One output element: (local channel col, sample tl of the channel's run) -> LDS tile [phase row][column], Snake, store.
+        auto shuffle_one = [&](int col, int tl) __attribute__((always_inline)) {
+            const int nl = tl / S, rr = tl - nl * S;
+            const int co = (m0 + tile_row(col * S)) / S;
+            int t = t_base + tl;
+            bool ok = co < a.Cout && n0 + nl < a.Ncols && t >= 0 && (a.up_per_out ? true : t < a.Tout);
+            int bb = b;
+            if (ok && a.up_per_out) {                                 // packed input rows -> unpacked output
+                const int sg = (int)__umulhi((unsigned)t, a.up_magic);
+                t -= sg * a.up_per_out;
+                bb = b * a.up_seg + sg;
+                ok = t < a.up_valid_out && bb < a.up_btrue;
+            }
+            if (ok) {
+                float v = Ct[(col * S + rr) * C::BNP + nl] + (ep_bias ? ep_bias[co] : 0.0f);
+                const size_t off = ((size_t)bb * a.Cout + co) * a.Tout + t;
+                const bool tail = a.tvalid && t >= a.tvalid;
+                const int lr = tile_row(col * S);                     // any phase row of this channel: same table entry
+                if (a.y2) a.y2[off] = tail ? 0.0f : det_snake(v, a.alpha2[co], Ep[C::BM + lr]);
+                if (snake_out) v = det_snake(v, a.alpha_out[co], Ep[lr]);
+                a.y[off] = tail ? 0.0f : v;
+            }
+        };
+        // 16-byte form (round 4): with 16-byte output rows a channel's run splits into `lead` head samples (they complete the
+        // previous tile's last quad in memory), QF aligned quads and a tail; a thread takes a whole quad -- four LDS reads at
+        // compile-time (phase, column) patterns, ONE bias / alpha / reciprocal fetch, one 16-byte store per output -- and the
+        // few head / tail samples go one by one.  (Before: every sample paid its own index arithmetic, its own global loads of
+        // bias and alpha and a 4-byte store.)
+        const bool up_quads = a.ovec4 && (C::BN * S) % 4 == 0 && (a.up_per_out == 0 || (a.up_per_out % 4 == 0 && a.up_valid_out % 4 == 0));
+        if (up_quads) {
+            const int lead = (4 - (t_base & 3)) & 3;                  // samples in front of the first 16-byte boundary
+            const int QF = (run - lead) / 4;
+            const int totq = nco * QF;
+            for (int e = tid; e < totq; e += C::NTHR) {
+                const int col = e / QF;
+                const int tl0 = lead + 4 * (e - col * QF);
+                const int co = (m0 + tile_row(col * S)) / S;
+                int t = t_base + tl0;                                 // multiple of 4
+                const int nl_last = (tl0 + 3) / S;
+                bool ok = co < a.Cout && n0 + nl_last < a.Ncols && t >= 0 && (a.up_per_out ? true : t + 3 < a.Tout);
+                int bb = b;
+                if (ok && a.up_per_out) {                             // quads never straddle a segment (period, valid % 4 == 0)
+                    const int sg = (int)__umulhi((unsigned)t, a.up_magic);
+                    t -= sg * a.up_per_out;
+                    bb = b * a.up_seg + sg;
+                    ok = t < a.up_valid_out && bb < a.up_btrue;
+                } else if (!ok && co < a.Cout) {                      // a quad cut by the end of the row: sample by sample
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) shuffle_one(col, tl0 + i);
+                    continue;
+                }
+                if (!ok) continue;
+                const float bv = ep_bias ? ep_bias[co] : 0.0f;
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int tl = tl0 + i, nl = tl / S, rr = tl - nl * S;
+                    v[i] = Ct[(col * S + rr) * C::BNP + nl] + bv;
+                }
+                const size_t off = ((size_t)bb * a.Cout + co) * a.Tout + t;
+                const int lr = tile_row(col * S);
+                int nz = (a.tvalid && t + 4 > a.tvalid) ? t + 4 - a.tvalid : 0;
+                nz = nz > 4 ? 4 : nz;
+                if (a.y2) {
+                    const float a2 = a.alpha2[co], i2 = Ep[C::BM + lr];
+                    f32x4 w = {det_snake(v.x, a2, i2), det_snake(v.y, a2, i2), det_snake(v.z, a2, i2), det_snake(v.w, a2, i2)};
+                    if (nz > 0) { w.w = 0.0f; if (nz > 1) w.z = 0.0f; if (nz > 2) w.y = 0.0f; if (nz > 3) w.x = 0.0f; }
+                    *reinterpret_cast<f32x4*>(a.y2 + off) = w;
+                }
+                if (snake_out) {
+                    const float al = a.alpha_out[co], inv = Ep[lr];
+                    v.x = det_snake(v.x, al, inv); v.y = det_snake(v.y, al, inv); v.z = det_snake(v.z, al, inv); v.w = det_snake(v.w, al, inv);
+                }
+                if (nz > 0) { v.w = 0.0f; if (nz > 1) v.z = 0.0f; if (nz > 2) v.y = 0.0f; if (nz > 3) v.x = 0.0f; }
+                *reinterpret_cast<f32x4*>(a.y + off) = v;
+            }
+            const int rest = run - 4 * QF;                            // head + tail samples of every channel
+            for (int e = tid; e < nco * rest; e += C::NTHR) {
+                const int col = e / rest, r = e - col * rest;
+                shuffle_one(col, r < lead ? r : 4 * QF + r);
+            }
+        } else
         for (int e = tid; e < total; e += C::NTHR) {
             const int col = e / run;
             const int tl = e - col * run;
