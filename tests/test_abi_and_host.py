@@ -203,3 +203,28 @@ def test_reference_shaped_checkpoints_load(tmp_path):
     da, dt = mvq.DAC(), mvq.DAC()
     n3 = mvq.AllPredAR3(da.encoder, da.quantizer, dt.encoder, dt.decoder, 1024)
     n3.load_state_dict(synth.proposed_model_state(3, rvq_books=10, rvq_embed=128), strict=True)
+
+
+def test_vpacked_geometry_and_argument_checks():
+    """Host side of the virtually packed rows (round 4): the geometry helper and the C entry point's argument validation
+    (refused before any device access, so it runs without a GPU)."""
+    from multimodal_vqvae_compression_audio_tactile_amd import _lib, ops
+    # the encoder tail at 24 kHz: k 16, s 8, pad 4 over 600 columns -> 75 valid outputs in 76-float rows, input period 608
+    assert ops.vpacked_geometry(600, 600, 16, 8, 1, 4, follow_pad=1) == (75, 76, 608)
+    # the k3 conv behind it: rows -> rows
+    assert ops.vpacked_geometry(76, 75, 3, 1, 1, 1, follow_pad=0) == (75, 76, 76)
+    assert ops.vpacked_geometry(602, 602, 16, 8, 1, 4) is None                       # rows that are not 16-byte multiples
+    # a longer clip: the period grows with the row, the gap always covers pad and the last output's overhang
+    for tin in (600, 608, 1200, 2400):
+        tout, rows, per_in = ops.vpacked_geometry(tin, tin, 16, 8, 1, 4, follow_pad=1)
+        assert tout == ops.conv1d_out_len(tin, 16, 8, 1, 4) and rows % 4 == 0 and per_in == 8 * rows
+        assert per_in - tin >= 4 and rows >= tout + 1
+    lib = _lib.lib()
+    bad = lambda *a: lib.mvq_conv1d_vpacked_f32(None, None, None, None, None, None, None, None, *a, None)
+    #              batch cin tin_rows tin_valid cout ks stride dil pad act seg per_in tout_rows
+    assert bad(4, 512, 600, 600, 1024, 16, 8, 1, 4, 0, 10, 600, 75) == -1 and b"per_in" in lib.mvq_last_error()      # tout_rows % 4
+    assert bad(4, 512, 600, 600, 1024, 16, 8, 1, 4, 0, 10, 608, 72) == -1                                             # per_in != s * rows
+    assert bad(4, 512, 600, 600, 1024, 16, 8, 1, 4, 0, 10, 576, 72) == -1                                             # rows longer than the period
+    assert bad(4, 512, 76, 76, 1024, 3, 1, 1, 1, 0, 10, 76, 76) == -1                                                 # no zero gap for the padding
+    assert bad(4, 512, 600, 600, 1024, 16, 8, 1, 4, 0, 10, 608, 76) == -1 and b"null tensor" in lib.mvq_last_error()  # geometry fine
+    assert bad(0, 512, 600, 600, 1024, 16, 8, 1, 4, 0, 10, 608, 76) == 0                                              # empty batch
