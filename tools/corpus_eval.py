@@ -75,18 +75,21 @@ def main():
     n_seg = int(first[-1])
     mine = set(mdist.shard_round_robin(n_seg, rank, world))
     a_segs, t_segs = [], []
+    gdev = torch.Generator(device=dev)
     t0 = time.perf_counter()
     for c in range(args.clips):
         ids = [i for i in range(int(first[c]), int(first[c + 1])) if i in mine]
         if not ids:
             continue
         dur = lens24[c] / 24000.0
-        g = torch.Generator().manual_seed(1000 + c)
+        # synthetic "recordings" at the corpus' native rates (3 kHz tactile, 44.1 kHz audio), drawn ON the device from a per-clip
+        # seed (round 3 drew them on the host and copied: 11 s of the tool's wall clock for 4 s of codec work)
+        gdev.manual_seed(1000 + c)
         n3, n44 = int(round(dur * 3000)), int(round(dur * 44100))
-        t3 = torch.cumsum(torch.randn(1, n3, generator=g), -1); t3 = t3 - t3.mean(); t3 = 0.9 * t3 / t3.abs().max().clamp_min(1e-6)
-        a44 = torch.randn(1, n44, generator=g); a44 = 0.9 * a44 / a44.abs().max()
-        t24 = up_t(t3.to(dev)).clamp(-1, 1)[..., :lens24[c]]
-        a24 = up_a(a44.to(dev)).clamp(-1, 1)[..., :lens24[c]]
+        t3 = torch.cumsum(torch.randn(1, n3, generator=gdev, device=dev), -1); t3 = t3 - t3.mean(); t3 = 0.9 * t3 / t3.abs().max().clamp_min(1e-6)
+        a44 = torch.randn(1, n44, generator=gdev, device=dev); a44 = 0.9 * a44 / a44.abs().max()
+        t24 = up_t(t3).clamp(-1, 1)[..., :lens24[c]]
+        a24 = up_a(a44).clamp(-1, 1)[..., :lens24[c]]
         L = min(t24.shape[-1], a24.shape[-1])
         need = int(seg_of_clip[c]) * SEG - L
         t24, a24 = reflect_pad_right(t24[..., :L], need), reflect_pad_right(a24[..., :L], need)
