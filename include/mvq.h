@@ -187,6 +187,16 @@ int mvq_dac_rvq_f32(const float* z, const float* in_w, const float* in_b, const 
 int mvq_dac_rvq_items_f32(const float* z, const float* in_w, const float* in_b, const float* codebook,
                           const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
                           const int32_t* nq_item, int batch, int c, int t, int nq_use, int k, int dc, void* stream);
+/* One-off preparation of the quantiser's codebooks (model load time, like the weight-norm fold): cb_normalised[nq,K,Dc] =
+ * F.normalize(codebook) and cb_norm2[nq,K] = its squared norms, by the same divisions / fma chains the search kernel would
+ * otherwise redo in every block of every call (a fifth of its vector instructions).  mvq_dac_rvq_prepared_f32 is
+ * mvq_dac_rvq_items_f32 with those two tensors handed in (both NULL = normalise in the kernel): bit-identical outputs. */
+int mvq_dac_rvq_prepare_f32(const float* codebook, float* cb_normalised, float* cb_norm2, int nq, int k, int dc, void* stream);
+int mvq_dac_rvq_prepared_f32(const float* z, const float* in_w, const float* in_b, const float* codebook,
+                             const float* cb_normalised, const float* cb_norm2,
+                             const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
+                             const int32_t* nq_item, int batch, int c, int t, int nq_use, int k, int dc, void* stream);
+
 
 /* ---- predictor / glue primitives (CrossPredictor, TokenNorm, PosEnc1D) --------------------------- */
 

@@ -51,6 +51,8 @@ EXPORTS = {
     "mvq_rvq_ema_step_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_float, c_void_p]),
     "mvq_dac_rvq_f32": (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p]),
     "mvq_dac_rvq_items_f32": (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_void_p]),
+    "mvq_dac_rvq_prepare_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
+    "mvq_dac_rvq_prepared_f32": (c_int, [c_void_p] * 12 + [c_int] * 6 + [c_void_p]),
     "mvq_layernorm_c_f32": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_size_t] * 2 + [c_float, c_int, c_float, c_void_p]),
     "mvq_attention_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_size_t] * 4 + [c_void_p]),
     "mvq_align_xcorr_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -594,6 +594,25 @@ int mvq_dac_rvq_items_f32(const float* z, const float* in_w, const float* in_b, 
                           const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
                           const int32_t* nq_item, int batch, int c, int t, int nq_use, int k, int dc, void* stream)
 {
+    return mvq_dac_rvq_prepared_f32(z, in_w, in_b, codebook, nullptr, nullptr, out_w, out_b, zq, codes, latents, nq_item,
+                                    batch, c, t, nq_use, k, dc, stream);
+}
+
+int mvq_dac_rvq_prepare_f32(const float* codebook, float* cb_normalised, float* cb_norm2, int nq, int k, int dc, void* stream)
+{
+    if (nq < 0 || k <= 0 || dc <= 0) return fail(MVQ_EINVAL, "dac_rvq_prepare: bad shape");
+    if (nq == 0) return MVQ_OK;
+    if (!codebook || !cb_normalised || !cb_norm2) return fail(MVQ_EINVAL, "dac_rvq_prepare: null tensor");
+    hipError_t e = mvq::launch_dac_rvq_prepare(codebook, cb_normalised, cb_norm2, nq, k, dc, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "dac_rvq_prepare");
+}
+
+int mvq_dac_rvq_prepared_f32(const float* z, const float* in_w, const float* in_b, const float* codebook,
+                             const float* cb_normalised, const float* cb_norm2,
+                             const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
+                             const int32_t* nq_item, int batch, int c, int t, int nq_use, int k, int dc, void* stream)
+{
+    if ((cb_normalised != nullptr) != (cb_norm2 != nullptr)) return fail(MVQ_EINVAL, "dac_rvq: cb_normalised and cb_norm2 go together");
     if (batch < 0 || t < 0 || (c != 1024 && c != 512 && c != 256) || dc != 8 || (k * dc) % 4 != 0 || nq_use <= 0 || k <= 0 || dc <= 0 || dc > 16)
         return fail(MVQ_EINVAL, "dac_rvq: bad shape B=%d C=%d T=%d nq=%d K=%d Dc=%d (C in {256,512,1024}, Dc = 8)", batch, c, t, nq_use, k, dc);
     if (batch == 0 || t == 0) return MVQ_OK;
@@ -601,7 +620,8 @@ int mvq_dac_rvq_items_f32(const float* z, const float* in_w, const float* in_b, 
         return fail(MVQ_EINVAL, "dac_rvq: null tensor");
     const size_t lds = ((size_t)k * dc + k + (size_t)dc * c + 16 * (size_t)dc * 16 + 2 * (size_t)dc * 16 + 2 * 16 * 16) * sizeof(float);
     if (lds > 160 * 1024) return fail(MVQ_EUNSUPPORTED, "dac_rvq: K*Dc too large for LDS (%zu bytes)", lds);
-    hipError_t e = mvq::launch_dac_rvq(z, in_w, in_b, codebook, out_w, out_b, zq, codes, latents, nq_item, batch, c, t, nq_use, k, dc, S(stream));
+    hipError_t e = mvq::launch_dac_rvq(z, in_w, in_b, codebook, out_w, out_b, zq, codes, latents, nq_item, batch, c, t, nq_use, k, dc, S(stream),
+                                       cb_normalised, cb_norm2);
     return e == hipSuccess ? MVQ_OK : hipfail(e, "dac_rvq");
 }
 

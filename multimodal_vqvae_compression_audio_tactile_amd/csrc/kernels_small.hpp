@@ -98,5 +98,7 @@ hipError_t launch_ema_update(const float* z, const int32_t* idx, float* books, v
                              float decay, hipStream_t s);
 hipError_t launch_dac_rvq(const float* z, const float* in_w, const float* in_b, const float* cb, const float* out_w,
                           const float* out_b, float* zq, int32_t* codes, float* latents, const int32_t* nq_item,
-                          int B, int C, int T, int nq, int K, int Dc, hipStream_t s);
+                          int B, int C, int T, int nq, int K, int Dc, hipStream_t s,
+                          const float* cbn_pre = nullptr, const float* cn2_pre = nullptr);
+hipError_t launch_dac_rvq_prepare(const float* cb, float* cbn, float* cn2, int nq, int K, int Dc, hipStream_t s);
 }  // namespace mvq

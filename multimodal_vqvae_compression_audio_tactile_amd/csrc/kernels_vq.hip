@@ -678,7 +678,8 @@ __global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
     const float* __restrict__ z, const float* __restrict__ in_w, const float* __restrict__ in_b,
     const float* __restrict__ cb, const float* __restrict__ out_w, const float* __restrict__ out_b,
     float* __restrict__ zq, int32_t* __restrict__ codes, float* __restrict__ latents,
-    const int32_t* __restrict__ nq_item, int B, int T, int nq, int K)
+    const int32_t* __restrict__ nq_item, int B, int T, int nq, int K,
+    const float* __restrict__ cbn_pre, const float* __restrict__ cn2_pre)
 {
     constexpr int C = 16 * CPT;
     constexpr int Dc = DC;
@@ -715,10 +716,15 @@ __global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
     for (int st = 0; st < nq; ++st) {
         const float* cbs = cb + (size_t)st * K * Dc;
         __syncthreads();                               // previous stage done with cbn / wst
-        copy_to_lds_f4(cbn, cbs, K * Dc, tid);
+        // F.normalize(codebook) and its squared norms are the same for every block and every call: with a PREPARED codebook
+        // (mvq_dac_rvq_prepare_f32, one-off at model load: the identical divisions, done once) the block copies them; otherwise
+        // it normalises its LDS copy in place (~120 vector instructions per code -- a fifth of the stage -- per block and stage)
+        copy_to_lds_f4(cbn, cbn_pre ? cbn_pre + (size_t)st * K * Dc : cbs, K * Dc, tid);
+        if (cbn_pre) for (int k = tid; k < K; k += 256) cn2[k] = cn2_pre[(size_t)st * K + k];
         copy_weights_skewed<CPT, DC, false>(wst, in_w + (size_t)st * Dc * C, tid);
         __syncthreads();
         // normalised codebook (in place) + squared norms
+        if (!cbn_pre)
         for (int k = tid; k < K; k += 256) {
             float ss = 0.0f;
             for (int d = 0; d < Dc; ++d) { const float v = cbn[k * Dc + d]; ss = dfma(v, v, ss); }
@@ -809,10 +815,36 @@ __global__ __launch_bounds__(256, 2) void dac_rvq_kernel(
     }
 }
 
+// one thread per code of every stage: cbn = e / max(||e||, 1e-12), cn2 = sum_d cbn_d^2 (d ascending) -- the arithmetic of the
+// in-kernel normalisation above, so a prepared codebook gives bit-identical codes and latents
+__global__ __launch_bounds__(256) void dac_rvq_prepare_kernel(const float* __restrict__ cb, float* __restrict__ cbn,
+                                                              float* __restrict__ cn2, int total, int Dc)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= total) return;
+    const float* e = cb + (size_t)k * Dc;
+    float* o = cbn + (size_t)k * Dc;
+    float ss = 0.0f;
+    for (int d = 0; d < Dc; ++d) { const float v = e[d]; ss = dfma(v, v, ss); }
+    const float den = __builtin_fmaxf(__builtin_sqrtf(ss), 1e-12f);
+    float s2 = 0.0f;
+    for (int d = 0; d < Dc; ++d) { const float v = e[d] / den; o[d] = v; s2 = dfma(v, v, s2); }
+    cn2[k] = s2;
+}
+
+hipError_t launch_dac_rvq_prepare(const float* cb, float* cbn, float* cn2, int nq, int K, int Dc, hipStream_t s)
+{
+    const int total = nq * K;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(dac_rvq_prepare_kernel, dim3((total + 255) / 256), dim3(256), 0, s, cb, cbn, cn2, total, Dc);
+    return hipGetLastError();
+}
+
 template <int CPT, int DC>
 static hipError_t launch_dac_rvq_t(const float* z, const float* in_w, const float* in_b, const float* cb,
                                    const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
-                                   const int32_t* nq_item, int B, int T, int nq, int K, hipStream_t s)
+                                   const int32_t* nq_item, int B, int T, int nq, int K, hipStream_t s,
+                                   const float* cbn_pre = nullptr, const float* cn2_pre = nullptr)
 {
     constexpr int C = 16 * CPT;
     const int N = B * T;
@@ -821,20 +853,20 @@ static hipError_t launch_dac_rvq_t(const float* z, const float* in_w, const floa
     static BigLdsOptIn opt;                           // per (instantiation, device)
     if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((N + DQ_TOK - 1) / DQ_TOK), dim3(256), lds, s,
-                       z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K);
+                       z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K, cbn_pre, cn2_pre);
     return hipGetLastError();
 }
 
 hipError_t launch_dac_rvq(const float* z, const float* in_w, const float* in_b, const float* cb, const float* out_w,
                           const float* out_b, float* zq, int32_t* codes, float* latents, const int32_t* nq_item,
-                          int B, int C, int T, int nq, int K, int Dc, hipStream_t s)
+                          int B, int C, int T, int nq, int K, int Dc, hipStream_t s, const float* cbn_pre, const float* cn2_pre)
 {
     if (B * T == 0) return hipSuccess;
     if (Dc != 8) return hipErrorInvalidValue;
     switch (C) {
-        case 1024: return launch_dac_rvq_t<64, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K, s);
-        case 512:  return launch_dac_rvq_t<32, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K, s);
-        case 256:  return launch_dac_rvq_t<16, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K, s);
+        case 1024: return launch_dac_rvq_t<64, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K, s, cbn_pre, cn2_pre);
+        case 512:  return launch_dac_rvq_t<32, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K, s, cbn_pre, cn2_pre);
+        case 256:  return launch_dac_rvq_t<16, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K, s, cbn_pre, cn2_pre);
     }
     return hipErrorInvalidValue;
 }

@@ -520,7 +520,8 @@ class ResidualVectorQuantize(nn.Module):
             in_b = torch.stack([q.in_proj.bias.detach() for q in qs]).contiguous()
             out_b = torch.stack([q.out_proj.bias.detach() for q in qs]).contiguous()
             cb = torch.stack([q.codebook.weight.detach() for q in qs]).contiguous()
-            return in_w, in_b, cb, out_w, out_b
+            prep = ops.dac_rvq_prepare(cb) if cb.is_cuda else None          # normalised codebooks: once per weight version
+            return in_w, in_b, cb, out_w, out_b, prep
 
         params = [p for q in qs for p in (q.in_proj.weight_g, q.in_proj.weight_v, q.in_proj.bias,
                                           q.out_proj.weight_g, q.out_proj.weight_v, q.out_proj.bias,
@@ -530,7 +531,7 @@ class ResidualVectorQuantize(nn.Module):
     @torch.no_grad()
     def forward(self, z, n_quantizers: Optional[int] = None):
         nq = self.n_codebooks if n_quantizers is None else max(1, min(int(n_quantizers), self.n_codebooks))
-        in_w, in_b, cb, out_w, out_b = self._weights()
+        in_w, in_b, cb, out_w, out_b, prep = self._weights()
         nq_item = None
         if self.training:                                        # upstream ignores n_quantizers here and runs every stage
             nq = self.n_codebooks
@@ -541,7 +542,7 @@ class ResidualVectorQuantize(nn.Module):
             lim[:n_dropout] = dropout[:n_dropout]
             if n_dropout > 0:
                 nq_item = lim.to(torch.int32).to(z.device)
-        zq, codes, latents = ops.dac_rvq(z, in_w, in_b, cb, out_w, out_b, nq, nq_item=nq_item)
+        zq, codes, latents = ops.dac_rvq(z, in_w, in_b, cb, out_w, out_b, nq, nq_item=nq_item, prepared=prep)
         zero = torch.zeros((), device=zq.device)
         return zq, codes, latents, zero, zero.clone()
 

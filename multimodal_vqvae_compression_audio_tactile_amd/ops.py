@@ -287,9 +287,21 @@ def rvq_ema_step_(z_tokens, books, decay=0.99):
     return books
 
 
-def dac_rvq(z, in_w, in_b, codebook, out_w, out_b, n_q, nq_item=None):
+def dac_rvq_prepare(codebook):
+    """F.normalize(codebook[nq, K, Dc]) and its squared norms, once (model load): -> (cb_normalised, cb_norm2) for dac_rvq."""
+    codebook = _dev(codebook, "codebook")
+    nq, K, Dc = codebook.shape
+    cbn = torch.empty_like(codebook)
+    cn2 = torch.empty(nq, K, device=codebook.device, dtype=torch.float32)
+    check(_lib.lib().mvq_dac_rvq_prepare_f32(codebook.data_ptr(), cbn.data_ptr(), cn2.data_ptr(), nq, K, Dc, _stream()),
+          "mvq_dac_rvq_prepare_f32")
+    return cbn, cn2
+
+
+def dac_rvq(z, in_w, in_b, codebook, out_w, out_b, n_q, nq_item=None, prepared=None):
     """DAC ResidualVectorQuantize -> (z_q, codes int64 [B,nq,T], latents [B,nq*Dc,T]).  ``nq_item`` (int32 [B] on the
-    device): train-mode quantiser dropout -- item b's z_q sums only its first nq_item[b] stages."""
+    device): train-mode quantiser dropout -- item b's z_q sums only its first nq_item[b] stages.  ``prepared`` =
+    dac_rvq_prepare(codebook): the normalised codebook computed once instead of in every block (same results)."""
     z = _dev(z, "z")
     B, C, T = z.shape
     _, K, Dc = codebook.shape
@@ -298,9 +310,10 @@ def dac_rvq(z, in_w, in_b, codebook, out_w, out_b, n_q, nq_item=None):
     lat = torch.empty(B, n_q * Dc, T, device=z.device, dtype=torch.float32)
     if nq_item is not None and (nq_item.dtype != torch.int32 or nq_item.numel() != B or not nq_item.is_cuda):
         raise MvqError("dac_rvq: nq_item must be an int32 HIP tensor with one entry per batch item")
-    check(_lib.lib().mvq_dac_rvq_items_f32(z.data_ptr(), in_w.data_ptr(), in_b.data_ptr(), codebook.data_ptr(),
-                                           out_w.data_ptr(), out_b.data_ptr(), zq.data_ptr(), codes.data_ptr(),
-                                           lat.data_ptr(), _p(nq_item), B, C, T, n_q, K, Dc, _stream()), "mvq_dac_rvq_f32")
+    cbn, cn2 = prepared if prepared is not None else (None, None)
+    check(_lib.lib().mvq_dac_rvq_prepared_f32(z.data_ptr(), in_w.data_ptr(), in_b.data_ptr(), codebook.data_ptr(), _p(cbn), _p(cn2),
+                                              out_w.data_ptr(), out_b.data_ptr(), zq.data_ptr(), codes.data_ptr(),
+                                              lat.data_ptr(), _p(nq_item), B, C, T, n_q, K, Dc, _stream()), "mvq_dac_rvq_f32")
     return zq, codes.long(), lat
 
 

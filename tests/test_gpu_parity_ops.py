@@ -502,3 +502,24 @@ def test_encoder_virtually_packed_tail_is_bit_equal(dev):
     # a length whose latent rows do not qualify falls back silently to the plain plan
     x2 = synth.tactile_segments(33, seed=4, T=24000 - 320 * 3 + 16).to(dev)
     assert enc(x2).shape[0] == 33
+
+
+def test_dac_rvq_prepared_codebook_is_bit_identical(dev):
+    """mvq_dac_rvq_prepare_f32 + mvq_dac_rvq_prepared_f32 (normalised codebooks computed once at load time) == the in-kernel
+    normalisation: same codes, latents and z_q, bit for bit, also under per-item stage limits."""
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, C, T, nq, K, Dc = 5, 1024, 37, 6, 1024, 8
+    z = torch.randn(B, C, T, generator=g).to(dev)
+    in_w = (torch.randn(nq, Dc, C, generator=g) / 32).to(dev); in_b = (0.1 * torch.randn(nq, Dc, generator=g)).to(dev)
+    cb = torch.randn(nq, K, Dc, generator=g).to(dev)
+    cb[1, 7] = 0.0                                                               # a zero code: the 1e-12 clamp of F.normalize
+    out_w = (torch.randn(nq, C, Dc, generator=g) / 3).to(dev); out_b = (0.1 * torch.randn(nq, C, generator=g)).to(dev)
+    prep = ops.dac_rvq_prepare(cb)
+    assert prep[0].shape == cb.shape and prep[1].shape == (nq, K) and float(prep[1][1, 7]) == 0.0
+    lim = torch.tensor([6, 1, 3, 6, 2], dtype=torch.int32, device=dev)
+    for nq_item in (None, lim):
+        a = ops.dac_rvq(z, in_w, in_b, cb, out_w, out_b, nq, nq_item=nq_item)
+        b = ops.dac_rvq(z, in_w, in_b, cb, out_w, out_b, nq, nq_item=nq_item, prepared=prep)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
