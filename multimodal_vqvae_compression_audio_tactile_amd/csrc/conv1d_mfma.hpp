@@ -224,6 +224,45 @@ __device__ __forceinline__ void lgkm_wait_step(float (&av)[MT], float (&bv)[NT])
     else static_assert(MT + NT <= 5 || MT == 4 || NT == 4 || (MT == 3 && NT == 3), "unsupported operand shape");
 }
 
+// ---- LDS-DMA burst: N consecutive full pieces of one wave (destinations INC bytes apart) in ONE statement --------------------
+// M0 (the LDS destination base) is compiler-reserved: it is saved once, written before every piece, and restored before the
+// statement ends; `s_nop 0` is the wait state gfx9 needs between an SALU write of M0 and the LDS-DMA instruction that reads it
+// (the assembler pads nothing inside an asm string).  Round 4: one save / restore per BURST instead of per piece (a 7-tap chunk
+// issues 4 full pieces per wave: 14 instead of 20 instructions in the MFMA wave's stream); tools/isa_lint.py R4 checks the shape.
+#define MVQ_DMA_FIRST(i) "s_nop 0\n\tglobal_load_lds_dwordx4 %" #i ", off\n\t"
+#define MVQ_DMA_NEXT(i) "s_add_u32 m0, m0, %[inc]\n\t" MVQ_DMA_FIRST(i)
+#define MVQ_DMA_HEAD "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %[dst]\n\t"
+#define MVQ_DMA_TAIL "s_mov_b32 m0, %0"
+template <int N, int INC>
+__device__ __forceinline__ void lds_dma_burst(const float* const* src, unsigned dst)
+{
+    static_assert(N >= 1 && N <= 8, "pieces per burst");
+    unsigned keep;
+    if constexpr (N == 1)
+        asm volatile(MVQ_DMA_HEAD MVQ_DMA_FIRST(1) MVQ_DMA_TAIL : "=&s"(keep) : "v"(src[0]), [dst] "s"(dst), [inc] "n"(INC) : "memory", "scc");
+    else if constexpr (N == 2)
+        asm volatile(MVQ_DMA_HEAD MVQ_DMA_FIRST(1) MVQ_DMA_NEXT(2) MVQ_DMA_TAIL
+                     : "=&s"(keep) : "v"(src[0]), "v"(src[1]), [dst] "s"(dst), [inc] "n"(INC) : "memory", "scc");
+    else if constexpr (N == 3)
+        asm volatile(MVQ_DMA_HEAD MVQ_DMA_FIRST(1) MVQ_DMA_NEXT(2) MVQ_DMA_NEXT(3) MVQ_DMA_TAIL
+                     : "=&s"(keep) : "v"(src[0]), "v"(src[1]), "v"(src[2]), [dst] "s"(dst), [inc] "n"(INC) : "memory", "scc");
+    else if constexpr (N == 4)
+        asm volatile(MVQ_DMA_HEAD MVQ_DMA_FIRST(1) MVQ_DMA_NEXT(2) MVQ_DMA_NEXT(3) MVQ_DMA_NEXT(4) MVQ_DMA_TAIL
+                     : "=&s"(keep) : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), [dst] "s"(dst), [inc] "n"(INC) : "memory", "scc");
+    else if constexpr (N == 5)
+        asm volatile(MVQ_DMA_HEAD MVQ_DMA_FIRST(1) MVQ_DMA_NEXT(2) MVQ_DMA_NEXT(3) MVQ_DMA_NEXT(4) MVQ_DMA_NEXT(5) MVQ_DMA_TAIL
+                     : "=&s"(keep) : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), [dst] "s"(dst), [inc] "n"(INC) : "memory", "scc");
+    else if constexpr (N == 6)
+        asm volatile(MVQ_DMA_HEAD MVQ_DMA_FIRST(1) MVQ_DMA_NEXT(2) MVQ_DMA_NEXT(3) MVQ_DMA_NEXT(4) MVQ_DMA_NEXT(5) MVQ_DMA_NEXT(6) MVQ_DMA_TAIL
+                     : "=&s"(keep) : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), [dst] "s"(dst), [inc] "n"(INC) : "memory", "scc");
+    else if constexpr (N == 7)
+        asm volatile(MVQ_DMA_HEAD MVQ_DMA_FIRST(1) MVQ_DMA_NEXT(2) MVQ_DMA_NEXT(3) MVQ_DMA_NEXT(4) MVQ_DMA_NEXT(5) MVQ_DMA_NEXT(6) MVQ_DMA_NEXT(7) MVQ_DMA_TAIL
+                     : "=&s"(keep) : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), [dst] "s"(dst), [inc] "n"(INC) : "memory", "scc");
+    else
+        asm volatile(MVQ_DMA_HEAD MVQ_DMA_FIRST(1) MVQ_DMA_NEXT(2) MVQ_DMA_NEXT(3) MVQ_DMA_NEXT(4) MVQ_DMA_NEXT(5) MVQ_DMA_NEXT(6) MVQ_DMA_NEXT(7) MVQ_DMA_NEXT(8) MVQ_DMA_TAIL
+                     : "=&s"(keep) : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7]), [dst] "s"(dst), [inc] "n"(INC) : "memory", "scc");
+}
+
 template <int KS, int STRIDE, int DIL, int BM, int XP, int MT, int NT, int NS, int G>
 struct AsmOperandLoop {
     static constexpr int NG = (NS + G - 1) / G;
@@ -683,23 +722,20 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         // DMA instructions this wave really issues per chunk (the last one is skipped by waves whose 64 pieces all lie past the end)
         const int n_issue = (NU - 1) * C::NTHR + wave_u * 64 < C::DMA_NV ? NU : NU - 1;
+        // pieces every wave issues in full (the first NFULL of the NU): one burst; the last, partly empty piece on its own
+        constexpr int NFULL = C::DMA_NV / C::NTHR < NU ? C::DMA_NV / C::NTHR : NU;
         auto dma_chunk = [&](int stage) __attribute__((always_inline)) {
+            // wave-instruction u fills 1 KiB at stage base + (u*NTHR + wave*64) * 16 bytes
+            const unsigned dst0 = lds0 + (unsigned)(stage * C::DMA_STAGE_FLOATS * 4) + (unsigned)(wave_u * 64 * 16);
+            if constexpr (NFULL > 0) lds_dma_burst<NFULL, C::NTHR * 16>(src, dst0);
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                // this wave-instruction fills 1 KiB at stage base + (u*NTHR + wave*64) * 16 bytes
-                const unsigned dst = lds0 + (unsigned)(stage * C::DMA_STAGE_FLOATS * 4) + (unsigned)((u * C::NTHR + wave_u * 64) * 16);
-                // M0 (the LDS destination base) is compiler-reserved: it is saved, written and read inside ONE statement and
-                // restored before the statement ends; s_nop 0 = the wait state gfx9 needs between an SALU write of M0 and the
-                // LDS-DMA instruction that reads it (the assembler pads nothing inside an asm string).
-                if ((u + 1) * C::NTHR <= C::DMA_NV || live[u]) {
-                    unsigned keep;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(src[u]), "s"(dst) : "memory");
-                }
-#if !(defined(MVQ_EXP) && (MVQ_EXP & 64))               // timing build: pointers not advanced (same chunk re-read)
-                src[u] += step_b[u];
-#endif
+            for (int u = NFULL; u < NU; ++u) {
+                if (live[u]) lds_dma_burst<1, C::NTHR * 16>(src + u, dst0 + (unsigned)(u * C::NTHR * 16));
             }
+#if !(defined(MVQ_EXP) && (MVQ_EXP & 64))               // timing build: pointers not advanced (same chunk re-read)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) src[u] += step_b[u];
+#endif
         };
         [[maybe_unused]] auto mfma_chunk_dma = [&](int stage, bool issue_next, int next_stage) __attribute__((always_inline)) {
             const float* wsrc = smem + stage * C::DMA_STAGE_FLOATS + a_base;

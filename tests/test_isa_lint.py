@@ -81,6 +81,18 @@ def test_lint_checks_the_m0_sequence_of_the_lds_dma():
     assert any("(R4)" in b for b in isa_lint.lint_function("dma", _prog(no_restore)))
     stray = good[:5] + [("s_mov_b32", "m0, s3")] + good[5:]
     assert any("outside the LDS-DMA sequence" in b for b in isa_lint.lint_function("dma", _prog(stray)))
+    burst = [
+        ("s_mov_b32", "s9, m0"), ("s_mov_b32", "m0, s8"),
+        ("s_nop", "0"), ("global_load_lds_dwordx4", "v[66:67], off"), ("s_add_u32", "m0, m0, 0x1000"),
+        ("s_nop", "0"), ("global_load_lds_dwordx4", "v[68:69], off"), ("s_add_u32", "m0, m0, 0x1000"),
+        ("s_nop", "0"), ("global_load_lds_dwordx4", "v[70:71], off"),
+        ("s_mov_b32", "m0, s9"), ("s_endpgm", ""),
+    ]
+    assert isa_lint.lint_function("burst", _prog(burst)) == []
+    no_nop2 = [b for k, b in enumerate(burst) if k != 5]                     # second piece without its wait state
+    assert any("(R4)" in b for b in isa_lint.lint_function("burst", _prog(no_nop2)))
+    unrestored = burst[:10] + burst[11:]
+    assert any("(R4)" in b for b in isa_lint.lint_function("burst", _prog(unrestored)))
 
 
 def test_shipped_library_passes_the_isa_lint():

@@ -13,8 +13,8 @@ Checks (every kernel of the library unless noted):
       and the compiler's block placement are handled exactly; compiler-issued reads are judged by the same rule.
   R3  the MFMA conv kernels (every conv1d_mfma_kernel / residual_unit_kernel instantiation, LDS-DMA or register-staged) use no
       scratch: zero `scratch_` instructions, and a zero private segment / no VGPR spills in the metadata of the LDS-DMA ones.
-  R4  every `global_load_lds_dwordx4` sits in the exact sequence
-          s_mov_b32 sK, m0 / s_mov_b32 m0, sD / s_nop 0 / global_load_lds_dwordx4 ... / s_mov_b32 m0, sK
+  R4  every `global_load_lds_dwordx4` sits inside a burst of the exact shape
+          s_mov_b32 sK, m0 / s_mov_b32 m0, sD / { s_nop 0 / global_load_lds_dwordx4 ... / [s_add_u32 m0, m0, imm] }+ / s_mov_b32 m0, sK
       and no other instruction of such a kernel writes M0.
 
 Usage:  python tools/isa_lint.py [path/to/libmvq_hip.so] [--stats] [--kernel SUBSTR] [--dump DIR]
@@ -227,27 +227,43 @@ def lint_function(name: str, insns: list[tuple[int, str, str]]) -> list[str]:
         q2, succ = run_block(b, q)
         for sb in succ:
             work.append((sb, q2))
-    # ---- R4: the LDS-DMA sequence
+    # ---- R4: the LDS-DMA bursts.  A burst is
+    #     s_mov_b32 sK, m0 / s_mov_b32 m0, sD / { s_nop / global_load_lds_dwordx4 / [s_add_u32 m0, m0, imm] }+ / s_mov_b32 m0, sK
+    # every LDS-DMA instruction and every write of M0 of such a kernel must lie inside one.
+    is_dma = lambda op, args: op.startswith("global_load_lds") or (op.startswith("buffer_load") and " lds" in args)
+    writes_m0 = lambda op, args: op.startswith("s_") and args.replace(" ", "").startswith("m0,")
+    covered: set[int] = set()
+    i = 0
+    while i < len(insns):
+        addr, op, args = insns[i]
+        m = re.fullmatch(r"(s\d+), m0", args.strip()) if op == "s_mov_b32" else None
+        if m and i + 1 < len(insns) and insns[i + 1][1] == "s_mov_b32" and insns[i + 1][2].replace(" ", "").startswith("m0,"):
+            keep = m.group(1)
+            j = i + 2
+            ok, n = True, 0
+            while ok:
+                if j + 1 < len(insns) and insns[j][1] == "s_nop" and is_dma(insns[j + 1][1], insns[j + 1][2]):
+                    n += 1
+                    j += 2
+                    if j < len(insns) and insns[j][1] == "s_add_u32" and insns[j][2].replace(" ", "").startswith("m0,m0,"):
+                        j += 1
+                        continue
+                    break
+                ok = False
+            if ok and n > 0 and j < len(insns) and insns[j][1] == "s_mov_b32" and insns[j][2].replace(" ", "") == f"m0,{keep}":
+                covered.update(range(i, j + 1))
+                i = j + 1
+                continue
+        i += 1
+    has_dma = any(is_dma(op, args) for _, op, args in insns)
     for i, (addr, op, args) in enumerate(insns):
-        if op == "global_load_lds_dwordx4" or (op.startswith("global_load_lds") or (op.startswith("buffer_load") and " lds" in args)):
-            ok = i >= 3 and i + 1 < len(insns)
-            if ok:
-                (_, o3, a3), (_, o2, a2), (_, o1, a1), (_, on, an) = insns[i - 3], insns[i - 2], insns[i - 1], insns[i + 1]
-                save = re.fullmatch(r"(s\d+), m0", a3.strip()) if o3 == "s_mov_b32" else None
-                ok = bool(save) and o2 == "s_mov_b32" and a2.strip().startswith("m0,") and o1 == "s_nop" \
-                    and on == "s_mov_b32" and an.replace(" ", "") == f"m0,{save.group(1)}"
-            if not ok:
-                ctx = "; ".join(f"{o} {a}" for _, o, a in insns[max(0, i - 3):i + 2])
-                bad.append(f"{name}: LDS-DMA at {addr:#x} is not wrapped in save-M0 / write-M0 / s_nop / DMA / restore-M0: [{ctx}] (R4)")
-    has_dma = any(op.startswith("global_load_lds") for _, op, _ in insns)
-    if has_dma:
-        for i, (addr, op, args) in enumerate(insns):
-            if args.replace(" ", "").startswith("m0,") and op.startswith("s_"):
-                nxt = insns[i + 1] if i + 1 < len(insns) else (0, "", "")
-                prv = insns[i - 1] if i > 0 else (0, "", "")
-                in_seq = (nxt[1] == "s_nop" and i + 2 < len(insns) and insns[i + 2][1].startswith("global_load_lds")) or prv[1].startswith("global_load_lds")
-                if not in_seq:
-                    bad.append(f"{name}: {addr:#x} `{op} {args}` writes M0 outside the LDS-DMA sequence (R4)")
+        if i in covered:
+            continue
+        if is_dma(op, args):
+            ctx = "; ".join(f"{o} {a}" for _, o, a in insns[max(0, i - 3):i + 2])
+            bad.append(f"{name}: LDS-DMA at {addr:#x} is not inside a save-M0 / (write-M0, s_nop, DMA)+ / restore-M0 burst: [{ctx}] (R4)")
+        elif has_dma and writes_m0(op, args):
+            bad.append(f"{name}: {addr:#x} `{op} {args}` writes M0 outside the LDS-DMA sequence (R4)")
     return bad
 
 
