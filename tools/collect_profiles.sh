@@ -47,7 +47,7 @@ cp "$(ls $OUT/ks_train/*/*kernel_stats.csv | tail -1)" "$OUT/kernel_stats_train_
 
 echo "[6/8] stored bench lines (after the traffic table: kernels_unchanged_since_profile must read true)"
 python3 bench.py --steps 5 --warmup 2 > "$OUT/bench_default_B256.json" 2> "$OUT/bench_default.err" || exit 61
-python3 bench.py --workload train --steps 5 --warmup 3 --no-cpu-baseline > "$OUT/bench_train_B256.json" 2> "$OUT/bench_train.err" || exit 62
+python3 bench.py --workload train --steps 5 --warmup 3 > "$OUT/bench_train_B256.json" 2> "$OUT/bench_train.err" || exit 62
 
 echo "[7/8] latency + corpus"
 python3 tools/latency.py > "$OUT/latency_B1.json" 2> "$OUT/latency.err" || exit 71
