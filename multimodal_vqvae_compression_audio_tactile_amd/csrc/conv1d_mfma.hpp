@@ -1152,43 +1152,67 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvArgs& a)
                 const float* const ctq = Ct + q_r0 * C::BNP + 4 * q_c0;
                 const float* const tbq = Tb + q_r0;
                 const float* const epq = Ep + q_r0;
+                // The quad loop, instantiated per COMBINATION of the uniform epilogue options (MODE): inside a mode every option is a
+                // compile-time constant, so a quad carries no scalar compare / branch per option (round 4, SQ counters: 760 scalar
+                // and 80 vector instructions per quad-row of the C = 192 1x1 before; floor 52 vector).  MODE 0 keeps them all at
+                // run time (backward / tanh / GELU epilogues and anything not listed).
+                auto reg_quads = [&](auto MODE_) __attribute__((always_inline)) {
+                    constexpr int MODE = decltype(MODE_)::value;
+                    // MODE: 1 skip + dual output | 2 skip + output Snake | 3 output Snake | 4 dual output | 5 skip only | 6 bias only
+                    const bool f_dsn = MODE == 0 ? (a.dsn_src != nullptr) : false;
+                    const bool f_res = MODE == 0 ? has_res : (MODE == 1 || MODE == 2 || MODE == 5);
+                    const bool f_y2 = MODE == 0 ? (a.y2 != nullptr) : (MODE == 1 || MODE == 4);
+                    const bool f_so = MODE == 0 ? snake_out : (MODE == 2 || MODE == 3);
+                    const bool f_tanh = MODE == 0 ? do_tanh : false;
+                    const bool f_gelu = MODE == 0 ? do_gelu : false;
 #pragma unroll
-                for (int it = 0; it < RES_IT; ++it) {
-                    const int k = reg_k(it, hp), j = it % JN;          // compile-time after unrolling
-                    const int trow = q_r0 + k;
-                    if (q_nok[j] && m0 + trow < a.Mrows) {
-                        const unsigned toff = q_t0 + (unsigned)(k * a.Tout) + q_col[j];
-                        const float bv = tbq[k];
-                        f32x4 v = *reinterpret_cast<const f32x4*>(ctq + (it / JN) * RSTEP * C::BNP + 4 * CQ * j);
-                        v.x = v.x + bv; v.y = v.y + bv; v.z = v.z + bv; v.w = v.w + bv;
-                        if (a.dsn_src) {
-                            const float ad = a.dsn_alpha[m0 + trow], id = epq[2 * C::BM + k];
-                            const f32x4 sv = *reinterpret_cast<const f32x4*>(dsb + toff);
-                            v.x = v.x * det_dsnake(sv.x, ad, id); v.y = v.y * det_dsnake(sv.y, ad, id);
-                            v.z = v.z * det_dsnake(sv.z, ad, id); v.w = v.w * det_dsnake(sv.w, ad, id);
+                    for (int it = 0; it < RES_IT; ++it) {
+                        const int k = reg_k(it, hp), j = it % JN;          // compile-time after unrolling
+                        const int trow = q_r0 + k;
+                        if (q_nok[j] && m0 + trow < a.Mrows) {
+                            const unsigned toff = q_t0 + (unsigned)(k * a.Tout) + q_col[j];
+                            const float bv = tbq[k];
+                            f32x4 v = *reinterpret_cast<const f32x4*>(ctq + (it / JN) * RSTEP * C::BNP + 4 * CQ * j);
+                            v.x = v.x + bv; v.y = v.y + bv; v.z = v.z + bv; v.w = v.w + bv;
+                            if (f_dsn) {
+                                const float ad = a.dsn_alpha[m0 + trow], id = epq[2 * C::BM + k];
+                                const f32x4 sv = *reinterpret_cast<const f32x4*>(dsb + toff);
+                                v.x = v.x * det_dsnake(sv.x, ad, id); v.y = v.y * det_dsnake(sv.y, ad, id);
+                                v.z = v.z * det_dsnake(sv.z, ad, id); v.w = v.w * det_dsnake(sv.w, ad, id);
+                            }
+                            if (f_res) {
+                                const f32x4 rv = res_q[it];
+                                v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
+                            }
+                            const int z = nz[j];
+                            if (f_y2) {
+                                const float a2 = tbq[C::BM + k], i2 = epq[C::BM + k];
+                                f32x4 w = {det_snake(v.x, a2, i2), det_snake(v.y, a2, i2), det_snake(v.z, a2, i2), det_snake(v.w, a2, i2)};
+                                if (z > 0) { w.w = 0.0f; if (z > 1) w.z = 0.0f; if (z > 2) w.y = 0.0f; if (z > 3) w.x = 0.0f; }
+                                *reinterpret_cast<f32x4*>(y2b + toff) = w;
+                            }
+                            if (f_so) {
+                                const float al = tbq[C::BM + k], inv = epq[k];
+                                v.x = det_snake(v.x, al, inv); v.y = det_snake(v.y, al, inv);
+                                v.z = det_snake(v.z, al, inv); v.w = det_snake(v.w, al, inv);
+                            }
+                            if (f_tanh) { v.x = det_tanh(v.x); v.y = det_tanh(v.y); v.z = det_tanh(v.z); v.w = det_tanh(v.w); }
+                            if (f_gelu) { v.x = det_gelu(v.x); v.y = det_gelu(v.y); v.z = det_gelu(v.z); v.w = det_gelu(v.w); }
+                            if (z > 0) { v.w = 0.0f; if (z > 1) v.z = 0.0f; if (z > 2) v.y = 0.0f; if (z > 3) v.x = 0.0f; }
+                            *reinterpret_cast<f32x4*>(yb + toff) = v;
                         }
-                        if (has_res) {
-                            const f32x4 rv = res_q[it];
-                            v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
-                        }
-                        const int z = nz[j];
-                        if (a.y2) {
-                            const float a2 = tbq[C::BM + k], i2 = epq[C::BM + k];
-                            f32x4 w = {det_snake(v.x, a2, i2), det_snake(v.y, a2, i2), det_snake(v.z, a2, i2), det_snake(v.w, a2, i2)};
-                            if (z > 0) { w.w = 0.0f; if (z > 1) w.z = 0.0f; if (z > 2) w.y = 0.0f; if (z > 3) w.x = 0.0f; }
-                            *reinterpret_cast<f32x4*>(y2b + toff) = w;
-                        }
-                        if (snake_out) {
-                            const float al = tbq[C::BM + k], inv = epq[k];
-                            v.x = det_snake(v.x, al, inv); v.y = det_snake(v.y, al, inv);
-                            v.z = det_snake(v.z, al, inv); v.w = det_snake(v.w, al, inv);
-                        }
-                        if (do_tanh) { v.x = det_tanh(v.x); v.y = det_tanh(v.y); v.z = det_tanh(v.z); v.w = det_tanh(v.w); }
-                        if (do_gelu) { v.x = det_gelu(v.x); v.y = det_gelu(v.y); v.z = det_gelu(v.z); v.w = det_gelu(v.w); }
-                        if (z > 0) { v.w = 0.0f; if (z > 1) v.z = 0.0f; if (z > 2) v.y = 0.0f; if (z > 3) v.x = 0.0f; }
-                        *reinterpret_cast<f32x4*>(yb + toff) = v;
                     }
-                }
+                };
+                const bool plain = !a.dsn_src && !do_tanh && !do_gelu;
+                const bool hy2 = a.y2 != nullptr;
+                if (!plain) reg_quads(std::integral_constant<int, 0>{});
+                else if (has_res && hy2 && !snake_out) reg_quads(std::integral_constant<int, 1>{});
+                else if (has_res && !hy2 && snake_out) reg_quads(std::integral_constant<int, 2>{});
+                else if (!has_res && !hy2 && snake_out) reg_quads(std::integral_constant<int, 3>{});
+                else if (!has_res && hy2 && !snake_out) reg_quads(std::integral_constant<int, 4>{});
+                else if (has_res && !hy2 && !snake_out) reg_quads(std::integral_constant<int, 5>{});
+                else if (!has_res && !hy2 && !snake_out) reg_quads(std::integral_constant<int, 6>{});
+                else reg_quads(std::integral_constant<int, 0>{});
             }
             if (quads_done) {
             } else if (PRE_RES) {
