@@ -388,6 +388,26 @@ int mvq_conv_transpose1d_packed_rows_f32(const float* x, const float* wp, const 
                                          int cout, int stride, int pad, int seg_per_row, int seg_period, int seg_valid,
                                          int batch_out, void* stream);
 
+/* OPT-IN, NON-PARITY arithmetic mode "bf16x6" for the wide ResidualUnits' 7-tap dilated convs (upstream dac ResidualUnit,
+ * called through Training/compare_dacvsproposal_5.py:294-296,322): the default path above is an exact k-ordered fp32 fma chain;
+ * these three entry points are the one deliberate departure and nothing calls them unless the caller asks for the mode
+ * (Python: multimodal_vqvae_compression_audio_tactile_amd.set_arith("bf16x6")).  Every fp32 operand is split into three
+ * bf16 pieces (24 significant bits) and a product is six piece products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+ * fp32-ACCURATE (the dropped terms are < 2^-24 |ab|) but summed in another order than the contract, so NOT bit-identical to the
+ * oracle; it earns no parity claim and is reported as its own bench line (dtype "bf16x6").
+ *   mvq_bf16x3_split_f32        x[batch, c, t] fp32 -> xs (mvq_bf16x3_split_bytes bytes): [batch][c/8][3 pieces][t][8] bf16; c % 8 == 0
+ *   mvq_conv1d_k7_pack_bf16x3   folded weights w[cout, cin, 7] fp32 -> wq (mvq_conv1d_k7_bf16x3_packed_bytes bytes);
+ *                               cout % 128 == 0, cin % 16 == 0
+ *   mvq_conv1d_k7_bf16x6_f32    y[batch, cout, t] = snake_out(conv7_dil(xs) + bias), 'same' padding 3 * dil, dil in {1, 3, 9};
+ *                               xs already carries the input Snake (the producer's dual output); tvalid as for the
+ *                               zero-padded rows above (0 = every column is data); wide != 0 selects 256-column tiles. */
+size_t mvq_bf16x3_split_bytes(int batch, int c, int t);
+int mvq_bf16x3_split_f32(const float* x, void* xs, int batch, int c, int t, void* stream);
+size_t mvq_conv1d_k7_bf16x3_packed_bytes(int cout, int cin);
+int mvq_conv1d_k7_pack_bf16x3(const float* w, void* wq, int cout, int cin, void* stream);
+int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y,
+                             int batch, int cin, int t, int cout, int dil, int tvalid, int wide, void* stream);
+
 /* Polyphase sinc resampler: torchaudio.transforms.Resample(orig, new) as the reference
  * calls it on every file (Training/compare_dacvsproposal_5.py:110-113, Evaluation/dac_vcpwq_proposed6_latency.py:151-156).
  * orig/newf are the rates divided by their gcd, kern[newf][ks] the filter bank (ks = 2*width + orig),

@@ -234,6 +234,51 @@ static hipError_t dispatch_convtr(const mvq::ConvArgs& a, hipStream_t s)
     return mvq::launch_conv_tr(a, mvq::conv_tile_bm(a.Mrows), s);
 }
 
+/* ---- opt-in bf16x6 arithmetic mode (conv_k7_bf16.hip; include/mvq.h) ---- */
+size_t mvq_bf16x3_split_bytes(int batch, int c, int t)
+{
+    if (batch <= 0 || c <= 0 || t <= 0) return 0;
+    return (size_t)batch * c * t * 6;
+}
+int mvq_bf16x3_split_f32(const float* x, void* xs, int batch, int c, int t, void* stream)
+{
+    if (batch < 0 || c <= 0 || t < 0 || c % 8 != 0) return fail(MVQ_EINVAL, "bf16x3_split: bad shape B=%d C=%d T=%d (C %% 8 == 0)", batch, c, t);
+    if (batch == 0 || t == 0) return MVQ_OK;
+    if (!x || !xs) return fail(MVQ_EINVAL, "bf16x3_split: null tensor");
+    if ((reinterpret_cast<uintptr_t>(xs) & 15) != 0) return fail(MVQ_EINVAL, "bf16x3_split: xs must be 16-byte aligned");
+    const hipError_t e = mvq::launch_bf16x3_split(x, xs, batch, c, t, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "bf16x3_split");
+}
+size_t mvq_conv1d_k7_bf16x3_packed_bytes(int cout, int cin)
+{
+    if (cout <= 0 || cin <= 0 || cout % 128 != 0 || cin % 16 != 0) return 0;
+    return (size_t)cout * cin * 7 * 6;
+}
+int mvq_conv1d_k7_pack_bf16x3(const float* w, void* wq, int cout, int cin, void* stream)
+{
+    if (cout <= 0 || cin <= 0 || cout % 128 != 0 || cin % 16 != 0)
+        return fail(MVQ_EINVAL, "conv1d_k7_pack_bf16x3: Cout %d must be a multiple of 128 and Cin %d of 16", cout, cin);
+    if (!w || !wq) return fail(MVQ_EINVAL, "conv1d_k7_pack_bf16x3: null tensor");
+    if ((reinterpret_cast<uintptr_t>(wq) & 15) != 0) return fail(MVQ_EINVAL, "conv1d_k7_pack_bf16x3: wq must be 16-byte aligned");
+    const hipError_t e = mvq::launch_bf16x3_pack_k7(w, wq, cout, cin, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_k7_pack_bf16x3");
+}
+int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y,
+                             int batch, int cin, int t, int cout, int dil, int tvalid, int wide, void* stream)
+{
+    if (batch < 0 || cin <= 0 || cout <= 0 || t < 0 || cout % 128 != 0 || cin % 16 != 0)
+        return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: bad shape B=%d Cin=%d T=%d Cout=%d (Cout %% 128, Cin %% 16)", batch, cin, t, cout);
+    if (dil != 1 && dil != 3 && dil != 9) return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: dilation %d not in {1, 3, 9}", dil);
+    if (tvalid < 0 || tvalid > t) return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: tvalid %d outside [0, %d]", tvalid, t);
+    if (batch == 0 || t == 0) return MVQ_OK;
+    if (!xs || !wq || !y) return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: null tensor");
+    if (((reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(wq)) & 15) != 0)
+        return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: xs / wq must be 16-byte aligned");
+    if ((long long)batch * ((t + 127) / 128) > 0x7fffffffLL) return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: grid too large");
+    const hipError_t e = mvq::launch_conv_k7_bf16x6(xs, wq, bias, alpha_out, y, batch, cin, t, cout, dil, tvalid, wide, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_k7_bf16x6");
+}
+
 /* which kernel instantiation mvq_conv1d_f32 / mvq_conv_transpose1d_f32 launches for a shape (profiling aid):
  * runs the real dispatch in "name mode" */
 int mvq_conv_kernel_name(int batch, int cin, int cout, int ks, int stride, int dil, int transposed, int tin, char* buf, int len)

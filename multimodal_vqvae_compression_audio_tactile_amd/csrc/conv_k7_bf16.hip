@@ -1,0 +1,337 @@
+// conv_k7_bf16.hip -- OPT-IN, NON-PARITY arithmetic mode "bf16x6" for the wide ResidualUnits' 7-tap dilated convs.
+//
+// The default path computes every conv as an exact k-ordered fp32 fma chain on v_mfma_f32_32x32x2_f32 (include/mvq.h,
+// "Arithmetic contract").  This unit is the ONE deliberate departure, selected only through mvq_conv1d_k7_bf16x6_f32:
+// every fp32 operand is split into three bf16 pieces a = a0 + a1 + a2 (a0 = rne(a), a1 = rne(a - a0), a2 = rne(a - a0 - a1):
+// 24 significant bits, the two subtractions are exact), and a product a*b is evaluated as the six piece products
+// a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The dropped terms (a1b2,
+// a2b1, a2b2) are below 2^-24 |ab|: the truncation error of a 1 792-term sum is 35x below the rounding error of the fp32 chain
+// itself (tools/bf16x6_accuracy.py), but the summation ORDER differs from the contract, so results are fp32-accurate and NOT
+// bit-identical to the oracle.  Six bf16 MFMAs of K = 16 replace eight fp32 MFMAs of K = 2 at 1/16 the time per flop: 2.67x
+// the matrix rate for the same contraction.
+//
+// Data formats (both made on the device by the kernels below):
+//   split activations  xs: bf16 [B][C/8][3 pieces][T][8 channels]      (16 bytes = one (item, channel octet, piece, t))
+//   packed weights     wq: bf16 [Cout/128][Cin/16][7 taps][3 pieces][2 octets][128 rows][8 channels]   (12 288-byte slices)
+// GEMM view: M = output channels (A operand = weights), N = time, K walked as (16-channel block, tap); the MFMA's lane map
+// (lane l: row/column l & 31, k = 8 (l >> 5) + j) makes one operand fragment of one piece the 16 bytes of one channel octet at
+// one row / time step: a single conflict-free ds_read_b128 (consecutive lanes 16 bytes apart).  Both operands reach LDS by
+// global -> LDS DMA only (no register staging, no VALU in the K loop): the activation tile of a channel block (all seven
+// taps read it at offsets of tap * DIL) is double-buffered, the weight slices run through a ring of three.
+#include "conv1d_mfma.hpp"
+
+namespace mvq {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16b __attribute__((ext_vector_type(16)));
+
+// ---- operand preparation ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3(float a, __bf16& p0, __bf16& p1, __bf16& p2)
+{
+    p0 = (__bf16)a;
+    const float r1 = a - (float)p0;          // exact
+    p1 = (__bf16)r1;
+    const float r2 = r1 - (float)p1;         // exact
+    p2 = (__bf16)r2;
+}
+
+// x[B][C][T] fp32 -> xs[B][C/8][3][T][8] bf16.  One thread per (item, octet, t): eight strided loads (each coalesced across
+// the threads of a wave, which walk t), three 16-byte stores.
+__global__ void bf16x3_split_kernel(const float* __restrict__ x, bf16x8* __restrict__ xs, int C, int T, size_t total)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int t = (int)(gid % (size_t)T);
+    const size_t bo = gid / (size_t)T;               // item * (C/8) + octet
+    const float* src = x + bo * 8 * (size_t)T + t;
+    bf16x8 q0, q1, q2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 a, b, c;
+        split3(src[(size_t)j * T], a, b, c);
+        q0[j] = a; q1[j] = b; q2[j] = c;
+    }
+    bf16x8* dst = xs + bo * 3 * (size_t)T + t;
+    dst[0] = q0; dst[(size_t)T] = q1; dst[2 * (size_t)T] = q2;
+}
+
+// w[Cout][Cin][7] fp32 -> wq (layout above).  One thread per 16-byte fragment.
+__global__ void bf16x3_pack_k7_kernel(const float* __restrict__ w, bf16x8* __restrict__ wq, int Cout, int Cin, size_t total)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    // fragment index -> (mt, cb, tap, piece, h, m)
+    size_t r = gid;
+    const int m = (int)(r % 128); r /= 128;
+    const int h = (int)(r % 2); r /= 2;
+    const int p = (int)(r % 3); r /= 3;
+    const int tap = (int)(r % 7); r /= 7;
+    const int ncb = Cin / 16;
+    const int cb = (int)(r % (size_t)ncb);
+    const int mt = (int)(r / (size_t)ncb);
+    const int co = mt * 128 + m;
+    bf16x8 q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = cb * 16 + h * 8 + j;
+        __bf16 pc[3];
+        split3(w[((size_t)co * Cin + ci) * 7 + tap], pc[0], pc[1], pc[2]);
+        q[j] = pc[p];
+    }
+    wq[gid] = q;
+}
+
+// ---- the conv -----------------------------------------------------------------------------------------------------------------
+struct K7BfArgs {
+    const bf16x8* xs;       // split activations (already carry the input Snake)
+    const bf16x8* wq;       // packed split weights
+    const float* bias;      // [Cout] or null
+    const float* alpha_out; // [Cout] or null: Snake1d behind the conv
+    float* y;               // [B][Cout][T] fp32
+    int B, Cin, Cout, T;
+    int n_tiles;            // column tiles per item
+    int tvalid;             // > 0: columns >= tvalid are written as zeros (zero-padded rows, include/mvq.h)
+};
+
+template <int DIL, int WN>
+struct K7BfCfg {
+    static constexpr int NW = 2 * WN, NTHR = 64 * NW;
+    static constexpr int BM = 128, BN = 64 * WN;
+    static constexpr int XT = BN + 6 * DIL;                 // activation positions a tile needs
+    static constexpr int XPIECES = 6 * XT;                  // 16-byte pieces of one channel block's tile: [piece][octet][position]
+    static constexpr int XBYTES = XPIECES * 16;
+    static constexpr int WPIECES = 3 * 2 * 128;             // one (channel block, tap) weight slice
+    static constexpr int WBYTES = WPIECES * 16;
+    static constexpr int NUX = (XPIECES + NTHR - 1) / NTHR; // DMA instructions per wave for an activation tile (the last may be partial)
+    static constexpr int NUW = (WPIECES + NTHR - 1) / NTHR;
+    static constexpr int LDS_BYTES = 2 * XBYTES + 3 * WBYTES;
+    static_assert(WPIECES % 64 == 0, "weight slice = whole wave instructions");
+};
+
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int DIL, int WN>
+__global__ __attribute__((amdgpu_flat_work_group_size(1, 128 * WN), amdgpu_waves_per_eu(2)))
+void conv_k7_bf16x6_kernel(const K7BfArgs a)
+{
+    using C = K7BfCfg<DIL, WN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave_u / WN, wn = wave_u % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int bx = blockIdx.x;
+    const int b = bx / a.n_tiles, tile_n = bx - b * a.n_tiles;
+    const int n0 = tile_n * C::BN, mt = blockIdx.y, m0 = mt * C::BM;
+    const int t0 = n0 - 3 * DIL;                                   // input position of tile position 0
+    const int ncb = a.Cin / 16;
+    const int n_steps = ncb * 7;
+    const size_t T = (size_t)a.T;
+
+    // ---- per-lane DMA sources
+    // activation pieces: q = u * NTHR + tid -> (ph = piece * 2 + octet-of-the-block, tt); advance by two octets per channel block
+    const bf16x8* xsrc[C::NUX];
+    long long xstep[C::NUX];
+    bool xlive[C::NUX];
+#pragma unroll
+    for (int u = 0; u < C::NUX; ++u) {
+        const int q = u * C::NTHR + tid;
+        xlive[u] = q < C::XPIECES;
+        const int qq = xlive[u] ? q : C::XPIECES - 1;
+        const int ph = qq / C::XT, tt = qq - ph * C::XT;
+        const int p = ph >> 1, o = ph & 1;
+        const int t = t0 + tt;
+        const bool ok = t >= 0 && t < a.T;
+        xsrc[u] = ok ? a.xs + (((size_t)b * (a.Cin / 8) + o) * 3 + p) * T + t : reinterpret_cast<const bf16x8*>(g_zero16);
+        xstep[u] = ok ? (long long)(2 * 3) * (long long)T : 0;
+    }
+    // weight pieces: slice s of this row tile starts at wq + (mt * n_steps + s) * WPIECES
+    const bf16x8* wsrc[C::NUW];
+    bool wlive[C::NUW];
+#pragma unroll
+    for (int u = 0; u < C::NUW; ++u) {
+        const int q = u * C::NTHR + tid;
+        wlive[u] = q < C::WPIECES;
+        wsrc[u] = a.wq + (size_t)mt * n_steps * C::WPIECES + (wlive[u] ? q : 0);
+    }
+    const unsigned lds0 = (unsigned)(size_t)lds;
+    const unsigned wave_off = (unsigned)(wave_u * 64 * 16);
+    // how many DMA instructions THIS wave issues for a tile / a slice (the last one only by the waves that hold live pieces)
+    const int nx_issue = ((C::NUX - 1) * C::NTHR + wave_u * 64 < C::XPIECES) ? C::NUX : C::NUX - 1;
+    const int nw_issue = ((C::NUW - 1) * C::NTHR + wave_u * 64 < C::WPIECES) ? C::NUW : C::NUW - 1;
+
+    auto dma_x = [&](int buf) __attribute__((always_inline)) {
+        const unsigned dst = lds0 + (unsigned)(buf * C::XBYTES) + wave_off;
+        constexpr int NFULL = C::XPIECES / C::NTHR;
+        if constexpr (NFULL > 0) lds_dma_burst<NFULL, C::NTHR * 16>(reinterpret_cast<const float* const*>(xsrc), dst);
+#pragma unroll
+        for (int u = NFULL; u < C::NUX; ++u)
+            if (xlive[u]) lds_dma_burst<1, C::NTHR * 16>(reinterpret_cast<const float* const*>(xsrc + u), dst + (unsigned)(u * C::NTHR * 16));
+#pragma unroll
+        for (int u = 0; u < C::NUX; ++u) xsrc[u] += xstep[u];
+    };
+    auto dma_w = [&](int stage) __attribute__((always_inline)) {
+        const unsigned dst = lds0 + (unsigned)(2 * C::XBYTES + stage * C::WBYTES) + wave_off;
+        constexpr int NFULL = C::WPIECES / C::NTHR;
+        if constexpr (NFULL > 0) lds_dma_burst<NFULL, C::NTHR * 16>(reinterpret_cast<const float* const*>(wsrc), dst);
+#pragma unroll
+        for (int u = NFULL; u < C::NUW; ++u)
+            if (wlive[u]) lds_dma_burst<1, C::NTHR * 16>(reinterpret_cast<const float* const*>(wsrc + u), dst + (unsigned)(u * C::NTHR * 16));
+#pragma unroll
+        for (int u = 0; u < C::NUW; ++u) wsrc[u] += C::WPIECES;
+    };
+
+    f32x16b acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // LDS read bases (in 16-byte fragments): A = weights [piece][octet][128 rows], B = activations [piece][octet][XT positions]
+    const int a_frag = h * 128 + wm * 64 + l31;
+    const int b_frag = h * C::XT + wn * 64 + l31;
+    const bf16x8* const xl = reinterpret_cast<const bf16x8*>(lds);
+    const bf16x8* const wl = reinterpret_cast<const bf16x8*>(lds + 2 * C::XBYTES);
+
+    // ---- prologue: activation tile of block 0, weight slices 0 and 1
+    dma_x(0);
+    dma_w(0);
+    if (n_steps > 1) dma_w(1);
+
+    // One K step = one (channel block, tap).  Issue order of the DMA: slice s+2 at step s; the NEXT block's activation tile at tap 1
+    // (behind slice s+2).  vmcnt counts in order, so "slice s has landed" = at most the instructions issued after it are still
+    // outstanding: slice s+1, plus the next tile at taps 2 and 3.  Waiting for FEWER outstanding than that is always safe, so the
+    // counts below use this wave's own slice count and the tile's minimum (NUX - 1).
+    auto wait_slice = [&](bool next_slice, bool tile_behind) __attribute__((always_inline)) {
+        // outstanding allowed: next_slice ? nw_issue : 0, plus tile_behind ? NUX - 1 : 0
+        if (!next_slice) { vm_wait<0>(); return; }
+        if (tile_behind) {
+            if (nw_issue == C::NUW) vm_wait<C::NUW + C::NUX - 1>(); else vm_wait<(C::NUW > 0 ? C::NUW - 1 : 0) + C::NUX - 1>();
+        } else {
+            if (nw_issue == C::NUW) vm_wait<C::NUW>(); else vm_wait<(C::NUW > 0 ? C::NUW - 1 : 0)>();
+        }
+    };
+    (void)nx_issue;
+
+    int wst = 0;                                                 // ring stage of slice s
+    for (int cb = 0; cb < ncb; ++cb) {
+        const bool more_cb = cb + 1 < ncb;
+        const bf16x8* const xb = xl + (cb & 1) * C::XPIECES + b_frag;
+#pragma unroll
+        for (int tap = 0; tap < 7; ++tap) {
+            const int s = cb * 7 + tap;
+            wait_slice(s + 1 < n_steps, more_cb && (tap == 2 || tap == 3));
+            __syncthreads();                                     // slice s (and at tap 0 the tile) visible to every wave; stage (s+2)%3 free
+            if (s + 2 < n_steps) dma_w(wst >= 1 ? wst - 1 : 2);   // (s + 2) % 3
+            if (tap == 1 && more_cb) dma_x((cb + 1) & 1);
+            const bf16x8* const wb = wl + wst * C::WPIECES + a_frag;
+            bf16x8 af[2][3], bq[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i][p] = wb[p * 256 + i * 32];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bq[j][p] = xb[p * 2 * C::XT + j * 32 + tap * DIL];
+            }
+            // six piece products per (i, j), smallest first: (w2,x0) (w0,x2) (w1,x1) (w1,x0) (w0,x1) (w0,x0); the four accumulators
+            // rotate inside each product, so a dependent MFMA on one accumulator is four issues (128 cycles) behind its producer
+            constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PW[k]], bq[j][PX[k]], acc[i][j], 0, 0, 0);
+            wst = wst == 2 ? 0 : wst + 1;
+        }
+    }
+
+    // ---- epilogue straight from the accumulators: register r of a 32x32 tile is row (r & 3) + 8 (r >> 2) + 4 h, the lane is the
+    // column, so one store instruction writes two 128-byte row segments.  bias, then the Snake (the same det_snake as the exact path).
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float bv = a.bias ? a.bias[m] : 0.0f;
+            const float al = a.alpha_out ? a.alpha_out[m] : 1.0f;
+            const float inv = 1.0f / (al + 1e-9f);
+            float* const yrow = a.y + ((size_t)b * a.Cout + m) * T;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + l31;
+                float v = acc[i][j][r] + bv;
+                if (a.alpha_out) v = det_snake(v, al, inv);
+                if (a.tvalid > 0 && n >= a.tvalid) v = 0.0f;
+                if (n < a.T) yrow[n] = v;
+            }
+        }
+}
+
+template <int DIL, int WN>
+static hipError_t launch_k7bf(const K7BfArgs& a_in, hipStream_t s)
+{
+    using C = K7BfCfg<DIL, WN>;
+    K7BfArgs a = a_in;
+    a.n_tiles = (a.T + C::BN - 1) / C::BN;
+    auto kern = conv_k7_bf16x6_kernel<DIL, WN>;
+    {
+        static BigLdsOptIn opt;
+        const hipError_t e = opt.ensure(reinterpret_cast<const void*>(kern));
+        if (e != hipSuccess) return e;
+    }
+    int pi = -1;
+    if (prof_enabled()) {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "conv_k7_bf16x6_kernel<%d, %d>", DIL, WN);
+        const int cols = a.tvalid > 0 ? a.tvalid : a.T;
+        pi = prof_begin(nm, 2.0 * a.Cin * 7.0 * a.Cout * (double)cols * a.B, s);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.n_tiles * a.B), (unsigned)(a.Cout / 128)), dim3(C::NTHR), C::LDS_BYTES, s, a);
+    prof_end(pi, s);
+    return hipGetLastError();
+}
+
+hipError_t launch_bf16x3_split(const float* x, void* xs, int batch, int c, int t, hipStream_t s)
+{
+    const size_t total = (size_t)batch * (c / 8) * t;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(bf16x3_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, reinterpret_cast<bf16x8*>(xs), c, t, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_bf16x3_pack_k7(const float* w, void* wq, int cout, int cin, hipStream_t s)
+{
+    const size_t total = (size_t)(cout / 128) * (cin / 16) * 7 * 3 * 2 * 128;
+    hipLaunchKernelGGL(bf16x3_pack_k7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<bf16x8*>(wq), cout, cin, total);
+    return hipGetLastError();
+}
+
+// wide: 0 = 128-column tiles (4 waves, two blocks per CU), 1 = 256-column tiles (8 waves, one block per CU)
+hipError_t launch_conv_k7_bf16x6(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y, int batch, int cin,
+                                 int t, int cout, int dil, int tvalid, int wide, hipStream_t s)
+{
+    K7BfArgs a{};
+    a.xs = reinterpret_cast<const bf16x8*>(xs); a.wq = reinterpret_cast<const bf16x8*>(wq); a.bias = bias; a.alpha_out = alpha_out; a.y = y;
+    a.B = batch; a.Cin = cin; a.Cout = cout; a.T = t; a.tvalid = tvalid;
+    if (wide) {
+        switch (dil) {
+            case 1: return launch_k7bf<1, 4>(a, s);
+            case 3: return launch_k7bf<3, 4>(a, s);
+            case 9: return launch_k7bf<9, 4>(a, s);
+        }
+    } else {
+        switch (dil) {
+            case 1: return launch_k7bf<1, 2>(a, s);
+            case 3: return launch_k7bf<3, 2>(a, s);
+            case 9: return launch_k7bf<9, 2>(a, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace mvq

@@ -7,6 +7,8 @@ autocast, Evaluation/compare_dacvsproposal_5_eval.py:441) are widened to fp32: t
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -161,6 +163,58 @@ def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x
     else:
         h = conv1d(x, w7p, C, 7, bias=b7, dil=dil, pad=3 * dil, alpha_in=alpha_a, alpha_out=alpha_b, tvalid=tvalid)
     return conv1d(h, w1p, C, 1, bias=b1, residual=x, alpha_out=alpha_next, alpha_dual=alpha_dual, tvalid=tvalid)
+
+
+# ---- opt-in, NON-PARITY arithmetic mode "bf16x6" (include/mvq.h; csrc/conv_k7_bf16.hip) ------------------------------------------
+# The default ("f32") computes every conv as the exact fp32 fma chain of the arithmetic contract.  set_arith("bf16x6") routes the
+# 7-tap convs of the wide ResidualUnits (C a multiple of 128) through the three-piece bf16 split: fp32-accurate, not bit-identical.
+_ARITH = "f32"
+
+
+def set_arith(mode: str) -> None:
+    global _ARITH
+    if mode not in ("f32", "bf16x6"):
+        raise MvqError(f"set_arith: unknown mode {mode!r} (f32 | bf16x6)")
+    _ARITH = mode
+
+
+def get_arith() -> str:
+    return _ARITH
+
+
+def bf16x6_eligible(c: int) -> bool:
+    return _ARITH == "bf16x6" and c % 128 == 0
+
+
+def bf16x3_split(x):
+    """x[B, C, T] fp32 -> the three-piece bf16 image [B][C/8][3][T][8] (a flat int16 tensor)."""
+    x = _dev(x, "x")
+    B, C, T = x.shape
+    xs = torch.empty(B * C * T * 3, device=x.device, dtype=torch.int16)
+    check(_lib.lib().mvq_bf16x3_split_f32(x.data_ptr(), xs.data_ptr(), B, C, T, _stream()), "mvq_bf16x3_split_f32")
+    return xs
+
+
+def pack_conv1d_k7_bf16x3(w):
+    """Folded weights w[Cout, Cin, 7] fp32 -> the packed three-piece bf16 image of mvq_conv1d_k7_bf16x6_f32."""
+    w = _dev(w, "w").contiguous()
+    cout, cin, ks = w.shape
+    n = _lib.lib().mvq_conv1d_k7_bf16x3_packed_bytes(cout, cin)
+    if ks != 7 or n == 0:
+        raise MvqError(f"pack_conv1d_k7_bf16x3: needs [Cout % 128 == 0, Cin % 16 == 0, 7], got {tuple(w.shape)}")
+    wq = torch.empty(n // 2, device=w.device, dtype=torch.int16)
+    check(_lib.lib().mvq_conv1d_k7_pack_bf16x3(w.data_ptr(), wq.data_ptr(), cout, cin, _stream()), "mvq_conv1d_k7_pack_bf16x3")
+    return wq
+
+
+def conv1d_k7_bf16x6(xs, wq, batch, cin, t, cout, dil, bias=None, alpha_out=None, tvalid=0, wide=None):
+    """y[B, cout, t] = snake_out(conv7_dil(xs) + bias) on the bf16x6 matrix path; xs from bf16x3_split, wq from pack_conv1d_k7_bf16x3."""
+    y = torch.empty(batch, cout, t, device=xs.device, dtype=torch.float32)
+    if wide is None:
+        wide = int(os.environ.get("MVQ_BF16X6_WIDE", "0"))
+    check(_lib.lib().mvq_conv1d_k7_bf16x6_f32(xs.data_ptr(), wq.data_ptr(), _p(bias), _p(alpha_out), y.data_ptr(), batch, cin, t,
+                                              cout, dil, int(tvalid), int(wide), _stream()), "mvq_conv1d_k7_bf16x6_f32")
+    return y
 
 
 def conv_transpose1d(x, wp, cout, stride, pad, bias=None, alpha_in=None, alpha_out=None, alpha_dual=None, tout_rows=0,
