@@ -93,7 +93,7 @@ struct K7BfArgs {
     int tvalid;             // > 0: columns >= tvalid are written as zeros (zero-padded rows, include/mvq.h)
 };
 
-template <int DIL, int WN>
+template <int DIL, int WN, int NST>
 struct K7BfCfg {
     static constexpr int NW = 2 * WN, NTHR = 64 * NW;
     static constexpr int BM = 128, BN = 64 * WN;
@@ -104,17 +104,34 @@ struct K7BfCfg {
     static constexpr int WBYTES = WPIECES * 16;
     static constexpr int NUX = (XPIECES + NTHR - 1) / NTHR; // DMA instructions per wave for an activation tile (the last may be partial)
     static constexpr int NUW = (WPIECES + NTHR - 1) / NTHR;
-    static constexpr int LDS_BYTES = 2 * XBYTES + 3 * WBYTES;
+    // weight ring of NST stages: slice s + NST - 1 is issued at step s, so NST - 2 slices are in flight behind the one being
+    // multiplied.  The steps are short (24 MFMAs of 32 cycles per wave), so the ring has to be deep: bytes in flight per CU =
+    // inflow rate x L2 latency (Little), ~20 B/clk x ~3 000 clk with 128-column tiles.
+    static constexpr int LDS_BYTES = 2 * XBYTES + NST * WBYTES;
     static_assert(WPIECES % 64 == 0, "weight slice = whole wave instructions");
+    static_assert(NST >= 3 && NST <= 6, "the next activation tile is issued at tap 1 and must be older than slice 7 (cb + 1)");
+    static_assert((NST - 2) * NUW + NUX <= 31, "vmcnt immediates of vm_wait_dyn");
 };
 
 template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in [0, 31] (the count is an immediate of the instruction)
+__device__ __forceinline__ void vm_wait_dyn(int n)
+{
+    switch (n) {
+#define MVQ_VW(k) case k: vm_wait<k>(); break;
+        MVQ_VW(0) MVQ_VW(1) MVQ_VW(2) MVQ_VW(3) MVQ_VW(4) MVQ_VW(5) MVQ_VW(6) MVQ_VW(7) MVQ_VW(8) MVQ_VW(9) MVQ_VW(10) MVQ_VW(11)
+        MVQ_VW(12) MVQ_VW(13) MVQ_VW(14) MVQ_VW(15) MVQ_VW(16) MVQ_VW(17) MVQ_VW(18) MVQ_VW(19) MVQ_VW(20) MVQ_VW(21) MVQ_VW(22)
+        MVQ_VW(23) MVQ_VW(24) MVQ_VW(25) MVQ_VW(26) MVQ_VW(27) MVQ_VW(28) MVQ_VW(29) MVQ_VW(30)
+#undef MVQ_VW
+        default: vm_wait<31>(); break;
+    }
+}
 
-template <int DIL, int WN>
+template <int DIL, int WN, int NST>
 __global__ __attribute__((amdgpu_flat_work_group_size(1, 128 * WN), amdgpu_waves_per_eu(2)))
 void conv_k7_bf16x6_kernel(const K7BfArgs a)
 {
-    using C = K7BfCfg<DIL, WN>;
+    using C = K7BfCfg<DIL, WN, NST>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -196,23 +213,20 @@ void conv_k7_bf16x6_kernel(const K7BfArgs a)
     const bf16x8* const xl = reinterpret_cast<const bf16x8*>(lds);
     const bf16x8* const wl = reinterpret_cast<const bf16x8*>(lds + 2 * C::XBYTES);
 
-    // ---- prologue: activation tile of block 0, weight slices 0 and 1
+    // ---- prologue: activation tile of block 0, weight slices 0 .. NST-2 (n_steps >= 7 > NST - 1)
     dma_x(0);
-    dma_w(0);
-    if (n_steps > 1) dma_w(1);
+#pragma unroll
+    for (int k = 0; k < NST - 1; ++k) dma_w(k);
 
-    // One K step = one (channel block, tap).  Issue order of the DMA: slice s+2 at step s; the NEXT block's activation tile at tap 1
-    // (behind slice s+2).  vmcnt counts in order, so "slice s has landed" = at most the instructions issued after it are still
-    // outstanding: slice s+1, plus the next tile at taps 2 and 3.  Waiting for FEWER outstanding than that is always safe, so the
-    // counts below use this wave's own slice count and the tile's minimum (NUX - 1).
-    auto wait_slice = [&](bool next_slice, bool tile_behind) __attribute__((always_inline)) {
-        // outstanding allowed: next_slice ? nw_issue : 0, plus tile_behind ? NUX - 1 : 0
-        if (!next_slice) { vm_wait<0>(); return; }
-        if (tile_behind) {
-            if (nw_issue == C::NUW) vm_wait<C::NUW + C::NUX - 1>(); else vm_wait<(C::NUW > 0 ? C::NUW - 1 : 0) + C::NUX - 1>();
-        } else {
-            if (nw_issue == C::NUW) vm_wait<C::NUW>(); else vm_wait<(C::NUW > 0 ? C::NUW - 1 : 0)>();
-        }
+    // One K step = one (channel block, tap).  Issue order of the DMA: slice s + NST - 1 at step s; the NEXT block's activation tile at
+    // tap 1 (behind that step's slice).  vmcnt counts in order, so "slice s has landed" = at most the instructions issued after it
+    // are still outstanding: the slices s+1 .. s+NST-2 that exist, plus the next tile at taps 2 .. NST (it is younger than slice
+    // 7 cb + NST and older than slice 7 cb + NST + 1 <= 7 (cb + 1), so it has landed when the next block starts).  Waiting for FEWER
+    // outstanding than that is always safe: the tile counts with its minimum (NUX - 1).
+    auto wait_slice = [&](int s, bool tile_behind) __attribute__((always_inline)) {
+        int k = n_steps - 1 - s;
+        k = k < NST - 2 ? k : NST - 2;
+        vm_wait_dyn(k * nw_issue + (tile_behind ? C::NUX - 1 : 0));
     };
     (void)nx_issue;
 
@@ -223,9 +237,9 @@ void conv_k7_bf16x6_kernel(const K7BfArgs a)
 #pragma unroll
         for (int tap = 0; tap < 7; ++tap) {
             const int s = cb * 7 + tap;
-            wait_slice(s + 1 < n_steps, more_cb && (tap == 2 || tap == 3));
-            __syncthreads();                                     // slice s (and at tap 0 the tile) visible to every wave; stage (s+2)%3 free
-            if (s + 2 < n_steps) dma_w(wst >= 1 ? wst - 1 : 2);   // (s + 2) % 3
+            wait_slice(s, more_cb && tap >= 2 && tap <= NST);
+            __syncthreads();                                     // slice s (and at tap 0 the tile) visible to every wave; the stage of slice s-1 is free
+            if (s + NST - 1 < n_steps) dma_w(wst >= 1 ? wst - 1 : NST - 1);   // (s + NST - 1) % NST
             if (tap == 1 && more_cb) dma_x((cb + 1) & 1);
             const bf16x8* const wb = wl + wst * C::WPIECES + a_frag;
             bf16x8 af[2][3], bq[2][3];
@@ -246,7 +260,7 @@ void conv_k7_bf16x6_kernel(const K7BfArgs a)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PW[k]], bq[j][PX[k]], acc[i][j], 0, 0, 0);
-            wst = wst == 2 ? 0 : wst + 1;
+            wst = wst == NST - 1 ? 0 : wst + 1;
         }
     }
 
@@ -272,13 +286,13 @@ void conv_k7_bf16x6_kernel(const K7BfArgs a)
         }
 }
 
-template <int DIL, int WN>
+template <int DIL, int WN, int NST>
 static hipError_t launch_k7bf(const K7BfArgs& a_in, hipStream_t s)
 {
-    using C = K7BfCfg<DIL, WN>;
+    using C = K7BfCfg<DIL, WN, NST>;
     K7BfArgs a = a_in;
     a.n_tiles = (a.T + C::BN - 1) / C::BN;
-    auto kern = conv_k7_bf16x6_kernel<DIL, WN>;
+    auto kern = conv_k7_bf16x6_kernel<DIL, WN, NST>;
     {
         static BigLdsOptIn opt;
         const hipError_t e = opt.ensure(reinterpret_cast<const void*>(kern));
@@ -287,7 +301,7 @@ static hipError_t launch_k7bf(const K7BfArgs& a_in, hipStream_t s)
     int pi = -1;
     if (prof_enabled()) {
         char nm[96];
-        snprintf(nm, sizeof(nm), "conv_k7_bf16x6_kernel<%d, %d>", DIL, WN);
+        snprintf(nm, sizeof(nm), "conv_k7_bf16x6_kernel<%d, %d, %d>", DIL, WN, NST);
         const int cols = a.tvalid > 0 ? a.tvalid : a.T;
         pi = prof_begin(nm, 2.0 * a.Cin * 7.0 * a.Cout * (double)cols * a.B, s);
     }
@@ -318,17 +332,23 @@ hipError_t launch_conv_k7_bf16x6(const void* xs, const void* wq, const float* bi
     K7BfArgs a{};
     a.xs = reinterpret_cast<const bf16x8*>(xs); a.wq = reinterpret_cast<const bf16x8*>(wq); a.bias = bias; a.alpha_out = alpha_out; a.y = y;
     a.B = batch; a.Cin = cin; a.Cout = cout; a.T = t; a.tvalid = tvalid;
-    if (wide) {
+    if (wide == 2) {                                  // A/B: the 256-column tile with a ring of four
         switch (dil) {
-            case 1: return launch_k7bf<1, 4>(a, s);
-            case 3: return launch_k7bf<3, 4>(a, s);
-            case 9: return launch_k7bf<9, 4>(a, s);
+            case 1: return launch_k7bf<1, 4, 4>(a, s);
+            case 3: return launch_k7bf<3, 4, 4>(a, s);
+            case 9: return launch_k7bf<9, 4, 4>(a, s);
+        }
+    } else if (wide) {
+        switch (dil) {
+            case 1: return launch_k7bf<1, 4, 6>(a, s);
+            case 3: return launch_k7bf<3, 4, 6>(a, s);
+            case 9: return launch_k7bf<9, 4, 6>(a, s);
         }
     } else {
         switch (dil) {
-            case 1: return launch_k7bf<1, 2>(a, s);
-            case 3: return launch_k7bf<3, 2>(a, s);
-            case 9: return launch_k7bf<9, 2>(a, s);
+            case 1: return launch_k7bf<1, 2, 3>(a, s);
+            case 3: return launch_k7bf<3, 2, 3>(a, s);
+            case 9: return launch_k7bf<9, 2, 3>(a, s);
         }
     }
     return hipErrorInvalidValue;

@@ -96,6 +96,12 @@ class WNConv1d(_WNKeys, nn.Module):
     def folded_weight(self) -> torch.Tensor:
         return ops.weight_norm(self.weight_v.detach(), self.weight_g.detach())
 
+    def packed_bf16x3(self) -> torch.Tensor:
+        """Three-piece bf16 image of the folded 7-tap weights: the opt-in, non-parity "bf16x6" arithmetic mode only (ops.set_arith)."""
+        if not hasattr(self, "_packed_bf"):
+            self._packed_bf = _Packed()
+        return self._packed_bf.get((self.weight_g, self.weight_v), lambda: ops.pack_conv1d_k7_bf16x3(self.folded_weight()))
+
     def packed_dgrad(self) -> torch.Tensor:
         if not hasattr(self, "_packed_dg"):
             self._packed_dg = _Packed()
@@ -183,9 +189,11 @@ class ResidualUnit(nn.Module):
 
     def run(self, x, alpha_next=None, x_snaked=None, alpha_dual=None, tvalid=0):
         c7, c1 = self.block[1], self.block[3]
+        # opt-in "bf16x6" mode (ops.set_arith; NOT bit-identical to the oracle): the 7-tap conv of a wide unit on the bf16 matrix cores
+        w7q = c7.packed_bf16x3() if (x_snaked is not None and ops.bf16x6_eligible(c7.cin)) else None
         return ops.residual_unit(x, c7.packed(), c7.bias.detach(), self.block[0].flat(), self.block[2].flat(),
                                  c1.packed(), c1.bias.detach(), c7.dilation, alpha_next=alpha_next, x_snaked=x_snaked,
-                                 alpha_dual=alpha_dual, tvalid=tvalid)
+                                 alpha_dual=alpha_dual, tvalid=tvalid, w7q=w7q)
 
     def forward(self, x):
         return self.run(x)

@@ -149,16 +149,19 @@ def residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=N
     return y if alpha_dual is None else (y, y2)
 
 
-def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x_snaked=None, alpha_dual=None, tvalid=0):
+def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x_snaked=None, alpha_dual=None, tvalid=0, w7q=None):
     """x + conv1(snake(conv7_dil(snake(x)))) (+ the next Snake1d): one fused launch for C in {64,96,128}, else the
     two conv launches (Snake on load / on store in the first, skip + next Snake in the second's epilogue).
     x_snaked: snake_a(x) already produced by the previous layer's dual output (skips the staging-time Snake);
-    alpha_dual: also return snake(y_raw, alpha_dual) for the next unit -> (y, y2)."""
+    alpha_dual: also return snake(y_raw, alpha_dual) for the next unit -> (y, y2).
+    w7q: the three-piece bf16 image of the 7-tap weights -- given only in the opt-in "bf16x6" mode for a wide unit."""
     x = _dev(x, "x")
     B, C, T = x.shape
     if _lib.lib().mvq_residual_unit_scratch_floats(B, C, T, dil) == 0:
         return residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next, alpha_dual, tvalid, x_snaked)
-    if x_snaked is not None:
+    if x_snaked is not None and w7q is not None:      # opt-in bf16x6 mode (set_arith): non-parity, fp32-accurate
+        h = conv1d_k7_bf16x6(bf16x3_split(x_snaked), w7q, B, C, T, C, dil, bias=b7, alpha_out=alpha_b, tvalid=tvalid)
+    elif x_snaked is not None:
         h = conv1d(x_snaked, w7p, C, 7, bias=b7, dil=dil, pad=3 * dil, alpha_out=alpha_b, tvalid=tvalid)
     else:
         h = conv1d(x, w7p, C, 7, bias=b7, dil=dil, pad=3 * dil, alpha_in=alpha_a, alpha_out=alpha_b, tvalid=tvalid)
