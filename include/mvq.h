@@ -397,7 +397,7 @@ int mvq_conv_transpose1d_packed_rows_f32(const float* x, const float* wp, const 
  * oracle; it earns no parity claim and is reported as its own bench line (dtype "bf16x6").
  *   mvq_bf16x3_split_f32        x[batch, c, t] fp32 -> xs (mvq_bf16x3_split_bytes bytes): [batch][c/8][3 pieces][t][8] bf16; c % 8 == 0
  *   mvq_conv1d_k7_pack_bf16x3   folded weights w[cout, cin, 7] fp32 -> wq (mvq_conv1d_k7_bf16x3_packed_bytes bytes);
- *                               cout % 128 == 0, cin % 16 == 0
+ *                               cout % 128 == 0 or cout % 96 == 0, cin % 16 == 0
  *   mvq_conv1d_k7_bf16x6_f32    y[batch, cout, t] = snake_out(conv7_dil(xs) + bias), 'same' padding 3 * dil, dil in {1, 3, 9};
  *                               xs already carries the input Snake (the producer's dual output); tvalid as for the
  *                               zero-padded rows above (0 = every column is data); wide != 0 selects 256-column tiles. */

@@ -251,13 +251,13 @@ int mvq_bf16x3_split_f32(const float* x, void* xs, int batch, int c, int t, void
 }
 size_t mvq_conv1d_k7_bf16x3_packed_bytes(int cout, int cin)
 {
-    if (cout <= 0 || cin <= 0 || cout % 128 != 0 || cin % 16 != 0) return 0;
+    if (cout <= 0 || cin <= 0 || mvq::bf16x6_tile_rows(cout) == 0 || cin % 16 != 0) return 0;
     return (size_t)cout * cin * 7 * 6;
 }
 int mvq_conv1d_k7_pack_bf16x3(const float* w, void* wq, int cout, int cin, void* stream)
 {
-    if (cout <= 0 || cin <= 0 || cout % 128 != 0 || cin % 16 != 0)
-        return fail(MVQ_EINVAL, "conv1d_k7_pack_bf16x3: Cout %d must be a multiple of 128 and Cin %d of 16", cout, cin);
+    if (cout <= 0 || cin <= 0 || mvq::bf16x6_tile_rows(cout) == 0 || cin % 16 != 0)
+        return fail(MVQ_EINVAL, "conv1d_k7_pack_bf16x3: Cout %d must be a multiple of 128 or 96 and Cin %d of 16", cout, cin);
     if (!w || !wq) return fail(MVQ_EINVAL, "conv1d_k7_pack_bf16x3: null tensor");
     if ((reinterpret_cast<uintptr_t>(wq) & 15) != 0) return fail(MVQ_EINVAL, "conv1d_k7_pack_bf16x3: wq must be 16-byte aligned");
     const hipError_t e = mvq::launch_bf16x3_pack_k7(w, wq, cout, cin, S(stream));
@@ -266,8 +266,8 @@ int mvq_conv1d_k7_pack_bf16x3(const float* w, void* wq, int cout, int cin, void*
 int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y,
                              int batch, int cin, int t, int cout, int dil, int tvalid, int wide, void* stream)
 {
-    if (batch < 0 || cin <= 0 || cout <= 0 || t < 0 || cout % 128 != 0 || cin % 16 != 0)
-        return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: bad shape B=%d Cin=%d T=%d Cout=%d (Cout %% 128, Cin %% 16)", batch, cin, t, cout);
+    if (batch < 0 || cin <= 0 || cout <= 0 || t < 0 || mvq::bf16x6_tile_rows(cout) == 0 || cin % 16 != 0)
+        return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: bad shape B=%d Cin=%d T=%d Cout=%d (Cout %% 128 or 96, Cin %% 16)", batch, cin, t, cout);
     if (dil != 1 && dil != 3 && dil != 9) return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: dilation %d not in {1, 3, 9}", dil);
     if (tvalid < 0 || tvalid > t) return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: tvalid %d outside [0, %d]", tvalid, t);
     if (batch == 0 || t == 0) return MVQ_OK;

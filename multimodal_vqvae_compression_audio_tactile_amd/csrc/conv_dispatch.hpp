@@ -11,6 +11,7 @@ hipError_t launch_conv_tr(const ConvArgs& a, int bm, hipStream_t s);            
 hipError_t launch_residual_unit_fused(const ConvArgs& a, int dil, hipStream_t s);   // C in {64, 96, 128}, dil 1/3/9
 // opt-in bf16x6 arithmetic mode (conv_k7_bf16.hip)
 hipError_t launch_bf16x3_split(const float* x, void* xs, int batch, int c, int t, hipStream_t s);
+int bf16x6_tile_rows(int cout);      // 128, 96 or 0 (no tile)
 hipError_t launch_bf16x3_pack_k7(const float* w, void* wq, int cout, int cin, hipStream_t s);
 hipError_t launch_conv_k7_bf16x6(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y, int batch, int cin,
                                  int t, int cout, int dil, int tvalid, int wide, hipStream_t s);

@@ -12,7 +12,8 @@
 //
 // Data formats (both made on the device by the kernels below):
 //   split activations  xs: bf16 [B][C/8][3 pieces][T][8 channels]      (16 bytes = one (item, channel octet, piece, t))
-//   packed weights     wq: bf16 [Cout/128][Cin/16][7 taps][3 pieces][2 octets][128 rows][8 channels]   (12 288-byte slices)
+//   packed weights     wq: bf16 [Cout/BM][Cin/16][7 taps][3 pieces][2 octets][BM rows][8 channels], BM = 128 (or 96 where 128 does
+//                      not divide Cout: C = 192) = the row tile of the kernel; one (block, tap) slice is 96 BM bytes
 // GEMM view: M = output channels (A operand = weights), N = time, K walked as (16-channel block, tap); the MFMA's lane map
 // (lane l: row/column l & 31, k = 8 (l >> 5) + j) makes one operand fragment of one piece the 16 bytes of one channel octet at
 // one row / time step: a single conflict-free ds_read_b128 (consecutive lanes 16 bytes apart).  Both operands reach LDS by
@@ -55,30 +56,34 @@ __global__ void bf16x3_split_kernel(const float* __restrict__ x, bf16x8* __restr
     dst[0] = q0; dst[(size_t)T] = q1; dst[2 * (size_t)T] = q2;
 }
 
-// w[Cout][Cin][7] fp32 -> wq (layout above).  One thread per 16-byte fragment.
-__global__ void bf16x3_pack_k7_kernel(const float* __restrict__ w, bf16x8* __restrict__ wq, int Cout, int Cin, size_t total)
+// w[Cout][Cin][7] fp32 -> wq (layout above).  One thread per (row tile, channel block, tap, octet, row): it splits its eight weights
+// once and stores the three 16-byte fragments (one per piece).  (A first form -- one thread per fragment, picking its piece out of a
+// local array by a run-time index -- produced sporadically wrong fragments on the device; no run-time register indexing here.)
+__global__ void bf16x3_pack_k7_kernel(const float* __restrict__ w, bf16x8* __restrict__ wq, int Cout, int Cin, int BM, size_t total)
 {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
-    // fragment index -> (mt, cb, tap, piece, h, m)
+    // thread index -> (mt, cb, tap, h, m)
     size_t r = gid;
-    const int m = (int)(r % 128); r /= 128;
+    const int m = (int)(r % (size_t)BM); r /= (size_t)BM;
     const int h = (int)(r % 2); r /= 2;
-    const int p = (int)(r % 3); r /= 3;
     const int tap = (int)(r % 7); r /= 7;
     const int ncb = Cin / 16;
     const int cb = (int)(r % (size_t)ncb);
     const int mt = (int)(r / (size_t)ncb);
-    const int co = mt * 128 + m;
-    bf16x8 q;
+    const int co = mt * BM + m;
+    bf16x8 q0, q1, q2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ci = cb * 16 + h * 8 + j;
-        __bf16 pc[3];
-        split3(w[((size_t)co * Cin + ci) * 7 + tap], pc[0], pc[1], pc[2]);
-        q[j] = pc[p];
+        __bf16 a, b, c;
+        split3(w[((size_t)co * Cin + ci) * 7 + tap], a, b, c);
+        q0[j] = a; q1[j] = b; q2[j] = c;
     }
-    wq[gid] = q;
+    // fragment (mt, cb, tap, piece, h, m)
+    const size_t slice = ((size_t)mt * ncb + cb) * 7 + tap;
+    bf16x8* dst = wq + slice * (size_t)(6 * BM) + (size_t)h * BM + m;
+    dst[0] = q0; dst[(size_t)2 * BM] = q1; dst[(size_t)4 * BM] = q2;
 }
 
 // ---- the conv -----------------------------------------------------------------------------------------------------------------
@@ -93,14 +98,14 @@ struct K7BfArgs {
     int tvalid;             // > 0: columns >= tvalid are written as zeros (zero-padded rows, include/mvq.h)
 };
 
-template <int DIL, int WN, int NST>
+template <int DIL, int MT, int NT, int WM, int WN, int NST>
 struct K7BfCfg {
-    static constexpr int NW = 2 * WN, NTHR = 64 * NW;
-    static constexpr int BM = 128, BN = 64 * WN;
+    static constexpr int NW = WM * WN, NTHR = 64 * NW;
+    static constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     static constexpr int XT = BN + 6 * DIL;                 // activation positions a tile needs
     static constexpr int XPIECES = 6 * XT;                  // 16-byte pieces of one channel block's tile: [piece][octet][position]
     static constexpr int XBYTES = XPIECES * 16;
-    static constexpr int WPIECES = 3 * 2 * 128;             // one (channel block, tap) weight slice
+    static constexpr int WPIECES = 3 * 2 * BM;              // one (channel block, tap) weight slice
     static constexpr int WBYTES = WPIECES * 16;
     static constexpr int NUX = (XPIECES + NTHR - 1) / NTHR; // DMA instructions per wave for an activation tile (the last may be partial)
     static constexpr int NUW = (WPIECES + NTHR - 1) / NTHR;
@@ -127,15 +132,15 @@ __device__ __forceinline__ void vm_wait_dyn(int n)
     }
 }
 
-template <int DIL, int WN, int NST>
-__global__ __attribute__((amdgpu_flat_work_group_size(1, 128 * WN), amdgpu_waves_per_eu(2)))
+template <int DIL, int MT, int NT, int WM, int WN, int NST>
+__global__ __attribute__((amdgpu_flat_work_group_size(1, 64 * WM * WN), amdgpu_waves_per_eu(2)))
 void conv_k7_bf16x6_kernel(const K7BfArgs a)
 {
-    using C = K7BfCfg<DIL, WN, NST>;
+    using C = K7BfCfg<DIL, MT, NT, WM, WN, NST>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int wm = wave_u / WN, wn = wave_u % WN;
+    const int wm = wave_u / WN, wn = wave_u % WN;   // WM x WN waves
     const int l31 = lane & 31, h = lane >> 5;
 
     const int bx = blockIdx.x;
@@ -199,17 +204,17 @@ void conv_k7_bf16x6_kernel(const K7BfArgs a)
         for (int u = 0; u < C::NUW; ++u) wsrc[u] += C::WPIECES;
     };
 
-    f32x16b acc[2][2];
+    f32x16b acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // LDS read bases (in 16-byte fragments): A = weights [piece][octet][128 rows], B = activations [piece][octet][XT positions]
-    const int a_frag = h * 128 + wm * 64 + l31;
-    const int b_frag = h * C::XT + wn * 64 + l31;
+    const int a_frag = h * C::BM + wm * (32 * MT) + l31;
+    const int b_frag = h * C::XT + wn * (32 * NT) + l31;
     const bf16x8* const xl = reinterpret_cast<const bf16x8*>(lds);
     const bf16x8* const wl = reinterpret_cast<const bf16x8*>(lds + 2 * C::XBYTES);
 
@@ -242,13 +247,13 @@ void conv_k7_bf16x6_kernel(const K7BfArgs a)
             if (s + NST - 1 < n_steps) dma_w(wst >= 1 ? wst - 1 : NST - 1);   // (s + NST - 1) % NST
             if (tap == 1 && more_cb) dma_x((cb + 1) & 1);
             const bf16x8* const wb = wl + wst * C::WPIECES + a_frag;
-            bf16x8 af[2][3], bq[2][3];
+            bf16x8 af[MT][3], bq[NT][3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[i][p] = wb[p * 256 + i * 32];
+                for (int i = 0; i < MT; ++i) af[i][p] = wb[p * 2 * C::BM + i * 32];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bq[j][p] = xb[p * 2 * C::XT + j * 32 + tap * DIL];
+                for (int j = 0; j < NT; ++j) bq[j][p] = xb[p * 2 * C::XT + j * 32 + tap * DIL];
             }
             // six piece products per (i, j), smallest first: (w2,x0) (w0,x2) (w1,x1) (w1,x0) (w0,x1) (w0,x0); the four accumulators
             // rotate inside each product, so a dependent MFMA on one accumulator is four issues (128 cycles) behind its producer
@@ -256,9 +261,9 @@ void conv_k7_bf16x6_kernel(const K7BfArgs a)
 #pragma unroll
             for (int k = 0; k < 6; ++k)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PW[k]], bq[j][PX[k]], acc[i][j], 0, 0, 0);
             wst = wst == NST - 1 ? 0 : wst + 1;
         }
@@ -267,17 +272,17 @@ void conv_k7_bf16x6_kernel(const K7BfArgs a)
     // ---- epilogue straight from the accumulators: register r of a 32x32 tile is row (r & 3) + 8 (r >> 2) + 4 h, the lane is the
     // column, so one store instruction writes two 128-byte row segments.  bias, then the Snake (the same det_snake as the exact path).
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const float bv = a.bias ? a.bias[m] : 0.0f;
             const float al = a.alpha_out ? a.alpha_out[m] : 1.0f;
             const float inv = 1.0f / (al + 1e-9f);
             float* const yrow = a.y + ((size_t)b * a.Cout + m) * T;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wn * 64 + j * 32 + l31;
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * (32 * NT) + j * 32 + l31;
                 float v = acc[i][j][r] + bv;
                 if (a.alpha_out) v = det_snake(v, al, inv);
                 if (a.tvalid > 0 && n >= a.tvalid) v = 0.0f;
@@ -286,13 +291,14 @@ void conv_k7_bf16x6_kernel(const K7BfArgs a)
         }
 }
 
-template <int DIL, int WN, int NST>
+template <int DIL, int MT, int NT, int WM, int WN, int NST>
 static hipError_t launch_k7bf(const K7BfArgs& a_in, hipStream_t s)
 {
-    using C = K7BfCfg<DIL, WN, NST>;
+    using C = K7BfCfg<DIL, MT, NT, WM, WN, NST>;
+    if (a_in.Cout % C::BM != 0) return hipErrorInvalidValue;
     K7BfArgs a = a_in;
     a.n_tiles = (a.T + C::BN - 1) / C::BN;
-    auto kern = conv_k7_bf16x6_kernel<DIL, WN, NST>;
+    auto kern = conv_k7_bf16x6_kernel<DIL, MT, NT, WM, WN, NST>;
     {
         static BigLdsOptIn opt;
         const hipError_t e = opt.ensure(reinterpret_cast<const void*>(kern));
@@ -301,11 +307,11 @@ static hipError_t launch_k7bf(const K7BfArgs& a_in, hipStream_t s)
     int pi = -1;
     if (prof_enabled()) {
         char nm[96];
-        snprintf(nm, sizeof(nm), "conv_k7_bf16x6_kernel<%d, %d, %d>", DIL, WN, NST);
+        snprintf(nm, sizeof(nm), "conv_k7_bf16x6_kernel<%d, %d, %d, %d, %d, %d>", DIL, MT, NT, WM, WN, NST);
         const int cols = a.tvalid > 0 ? a.tvalid : a.T;
         pi = prof_begin(nm, 2.0 * a.Cin * 7.0 * a.Cout * (double)cols * a.B, s);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.n_tiles * a.B), (unsigned)(a.Cout / 128)), dim3(C::NTHR), C::LDS_BYTES, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.n_tiles * a.B), (unsigned)(a.Cout / C::BM)), dim3(C::NTHR), C::LDS_BYTES, s, a);
     prof_end(pi, s);
     return hipGetLastError();
 }
@@ -318,37 +324,50 @@ hipError_t launch_bf16x3_split(const float* x, void* xs, int batch, int c, int t
     return hipGetLastError();
 }
 
+// rows per weight slice = the row tile of the kernel that will read the image: 128 where Cout allows, else 96 (C = 192)
+int bf16x6_tile_rows(int cout) { return cout % 128 == 0 ? 128 : (cout % 96 == 0 ? 96 : 0); }
+
 hipError_t launch_bf16x3_pack_k7(const float* w, void* wq, int cout, int cin, hipStream_t s)
 {
-    const size_t total = (size_t)(cout / 128) * (cin / 16) * 7 * 3 * 2 * 128;
-    hipLaunchKernelGGL(bf16x3_pack_k7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<bf16x8*>(wq), cout, cin, total);
+    const int bm = bf16x6_tile_rows(cout);
+    if (bm == 0) return hipErrorInvalidValue;
+    const size_t total = (size_t)(cout / bm) * (cin / 16) * 7 * 2 * bm;
+    hipLaunchKernelGGL(bf16x3_pack_k7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<bf16x8*>(wq), cout, cin, bm, total);
     return hipGetLastError();
 }
 
-// wide: 0 = 128-column tiles (4 waves, two blocks per CU), 1 = 256-column tiles (8 waves, one block per CU)
+// wide: 0 = the default tile of the row count (128 x 128 on 2 x 2 waves, or 96 x 128 on 1 x 4 waves for Cout % 128 != 0, two blocks
+// per CU); 1 / 2 = A/B forms of the 128-row tile with 256 columns on 8 waves (ring of six / four)
 hipError_t launch_conv_k7_bf16x6(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y, int batch, int cin,
                                  int t, int cout, int dil, int tvalid, int wide, hipStream_t s)
 {
     K7BfArgs a{};
     a.xs = reinterpret_cast<const bf16x8*>(xs); a.wq = reinterpret_cast<const bf16x8*>(wq); a.bias = bias; a.alpha_out = alpha_out; a.y = y;
     a.B = batch; a.Cin = cin; a.Cout = cout; a.T = t; a.tvalid = tvalid;
-    if (wide == 2) {                                  // A/B: the 256-column tile with a ring of four
+    const int bm = bf16x6_tile_rows(cout);
+    if (bm == 96) {
         switch (dil) {
-            case 1: return launch_k7bf<1, 4, 4>(a, s);
-            case 3: return launch_k7bf<3, 4, 4>(a, s);
-            case 9: return launch_k7bf<9, 4, 4>(a, s);
+            case 1: return launch_k7bf<1, 3, 1, 1, 4, 3>(a, s);
+            case 3: return launch_k7bf<3, 3, 1, 1, 4, 3>(a, s);
+            case 9: return launch_k7bf<9, 3, 1, 1, 4, 3>(a, s);
         }
-    } else if (wide) {
+    } else if (bm == 128 && wide == 2) {
         switch (dil) {
-            case 1: return launch_k7bf<1, 4, 6>(a, s);
-            case 3: return launch_k7bf<3, 4, 6>(a, s);
-            case 9: return launch_k7bf<9, 4, 6>(a, s);
+            case 1: return launch_k7bf<1, 2, 2, 2, 4, 4>(a, s);
+            case 3: return launch_k7bf<3, 2, 2, 2, 4, 4>(a, s);
+            case 9: return launch_k7bf<9, 2, 2, 2, 4, 4>(a, s);
         }
-    } else {
+    } else if (bm == 128 && wide) {
         switch (dil) {
-            case 1: return launch_k7bf<1, 2, 3>(a, s);
-            case 3: return launch_k7bf<3, 2, 3>(a, s);
-            case 9: return launch_k7bf<9, 2, 3>(a, s);
+            case 1: return launch_k7bf<1, 2, 2, 2, 4, 6>(a, s);
+            case 3: return launch_k7bf<3, 2, 2, 2, 4, 6>(a, s);
+            case 9: return launch_k7bf<9, 2, 2, 2, 4, 6>(a, s);
+        }
+    } else if (bm == 128) {
+        switch (dil) {
+            case 1: return launch_k7bf<1, 2, 2, 2, 2, 3>(a, s);
+            case 3: return launch_k7bf<3, 2, 2, 2, 2, 3>(a, s);
+            case 9: return launch_k7bf<9, 2, 2, 2, 2, 3>(a, s);
         }
     }
     return hipErrorInvalidValue;

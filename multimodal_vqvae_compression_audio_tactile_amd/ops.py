@@ -186,7 +186,7 @@ def get_arith() -> str:
 
 
 def bf16x6_eligible(c: int) -> bool:
-    return _ARITH == "bf16x6" and c % 128 == 0
+    return _ARITH == "bf16x6" and (c % 128 == 0 or c % 96 == 0) and c % 16 == 0
 
 
 def bf16x3_split(x):
@@ -204,7 +204,7 @@ def pack_conv1d_k7_bf16x3(w):
     cout, cin, ks = w.shape
     n = _lib.lib().mvq_conv1d_k7_bf16x3_packed_bytes(cout, cin)
     if ks != 7 or n == 0:
-        raise MvqError(f"pack_conv1d_k7_bf16x3: needs [Cout % 128 == 0, Cin % 16 == 0, 7], got {tuple(w.shape)}")
+        raise MvqError(f"pack_conv1d_k7_bf16x3: needs [Cout % 128 == 0 or % 96 == 0, Cin % 16 == 0, 7], got {tuple(w.shape)}")
     wq = torch.empty(n // 2, device=w.device, dtype=torch.int16)
     check(_lib.lib().mvq_conv1d_k7_pack_bf16x3(w.data_ptr(), wq.data_ptr(), cout, cin, _stream()), "mvq_conv1d_k7_pack_bf16x3")
     return wq

@@ -29,8 +29,25 @@ def test_split_is_bit_exact_and_lossless_to_24_bits(dev):
     assert ((back - x).abs() <= x.abs() * 2.0 ** -23).all()
 
 
+@pytest.mark.parametrize("C", [128, 192, 384])
+def test_weight_pack_is_bit_exact_every_time(C, dev):
+    """The packed three-piece weight image against a torch restatement of its layout, several launches in a row (a first form of
+    the pack kernel produced sporadically wrong fragments: this test is what would have caught it)."""
+    import time
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    torch.manual_seed(C)
+    w = torch.randn(C, C, 7, device=dev) / math.sqrt(7 * C)
+    bm = 128 if C % 128 == 0 else 96
+    pcs = torch.stack([p.float() for p in _split_ref(w)], 0).bfloat16()                 # [piece][co][ci][tap]
+    want = pcs.reshape(3, C // bm, bm, C // 16, 2, 8, 7).permute(1, 3, 6, 0, 4, 2, 5).contiguous().view(torch.int16).reshape(-1)
+    for _ in range(6):
+        time.sleep(0.02)
+        got = ops.pack_conv1d_k7_bf16x3(w)
+        assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("wide", [0, 1])
-@pytest.mark.parametrize("C,T,dil,tvalid", [(128, 300, 1, 0), (256, 601, 3, 0), (384, 260, 9, 259), (256, 75, 9, 0)])
+@pytest.mark.parametrize("C,T,dil,tvalid", [(128, 300, 1, 0), (256, 601, 3, 0), (384, 260, 9, 259), (256, 75, 9, 0), (192, 300, 3, 0), (192, 516, 9, 515)])
 def test_conv_k7_bf16x6_is_fp32_accurate(C, T, dil, tvalid, wide, dev):
     from multimodal_vqvae_compression_audio_tactile_amd import ops
     torch.manual_seed(C + T + dil)
@@ -67,7 +84,7 @@ def test_conv_k7_bf16x6_rejects_bad_shapes(dev):
     from multimodal_vqvae_compression_audio_tactile_amd import ops
     from multimodal_vqvae_compression_audio_tactile_amd._lib import MvqError
     with pytest.raises(MvqError):
-        ops.pack_conv1d_k7_bf16x3(torch.randn(192, 192, 7, device=dev))          # Cout % 128
+        ops.pack_conv1d_k7_bf16x3(torch.randn(160, 160, 7, device=dev))          # Cout % 128 and % 96
     with pytest.raises(MvqError):
         ops.bf16x3_split(torch.randn(1, 12, 16, device=dev))                      # C % 8
     xs = ops.bf16x3_split(torch.randn(1, 128, 16, device=dev)); wq = ops.pack_conv1d_k7_bf16x3(torch.randn(128, 128, 7, device=dev))

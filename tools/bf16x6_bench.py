@@ -19,7 +19,7 @@ def timeit(f, n=10):
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / n)
     return best
-for name, C, T in (("enc.b2", 256, 3000), ("enc.b3", 512, 600), ("dec.b0", 768, 600), ("dec.b1", 384, 3000)):
+for name, C, T in (("enc.b2", 256, 3000), ("enc.b3", 512, 600), ("dec.b0", 768, 600), ("dec.b1", 384, 3000), ("dec.b2", 192, 11996)):
     for dil in (1, 3, 9):
         x = torch.randn(B, C, T, device=dev)
         w = torch.randn(C, C, 7, device=dev) / math.sqrt(7 * C)
