@@ -400,13 +400,13 @@ int mvq_conv_transpose1d_packed_rows_f32(const float* x, const float* wp, const 
  *                               cout % 128 == 0 or cout % 96 == 0, cin % 16 == 0
  *   mvq_conv1d_k7_bf16x6_f32    y[batch, cout, t] = snake_out(conv7_dil(xs) + bias), 'same' padding 3 * dil, dil in {1, 3, 9};
  *                               xs already carries the input Snake (the producer's dual output); tvalid as for the
- *                               zero-padded rows above (0 = every column is data); wide != 0 selects 256-column tiles. */
+ *                               zero-padded rows above (0 = every column is data). */
 size_t mvq_bf16x3_split_bytes(int batch, int c, int t);
 int mvq_bf16x3_split_f32(const float* x, void* xs, int batch, int c, int t, void* stream);
 size_t mvq_conv1d_k7_bf16x3_packed_bytes(int cout, int cin);
 int mvq_conv1d_k7_pack_bf16x3(const float* w, void* wq, int cout, int cin, void* stream);
 int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y,
-                             int batch, int cin, int t, int cout, int dil, int tvalid, int wide, void* stream);
+                             int batch, int cin, int t, int cout, int dil, int tvalid, void* stream);
 
 /* Polyphase sinc resampler: torchaudio.transforms.Resample(orig, new) as the reference
  * calls it on every file (Training/compare_dacvsproposal_5.py:110-113, Evaluation/dac_vcpwq_proposed6_latency.py:151-156).

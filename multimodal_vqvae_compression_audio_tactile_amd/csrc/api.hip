@@ -264,7 +264,7 @@ int mvq_conv1d_k7_pack_bf16x3(const float* w, void* wq, int cout, int cin, void*
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_k7_pack_bf16x3");
 }
 int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y,
-                             int batch, int cin, int t, int cout, int dil, int tvalid, int wide, void* stream)
+                             int batch, int cin, int t, int cout, int dil, int tvalid, void* stream)
 {
     if (batch < 0 || cin <= 0 || cout <= 0 || t < 0 || mvq::bf16x6_tile_rows(cout) == 0 || cin % 16 != 0)
         return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: bad shape B=%d Cin=%d T=%d Cout=%d (Cout %% 128 or 96, Cin %% 16)", batch, cin, t, cout);
@@ -275,7 +275,7 @@ int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, 
     if (((reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(wq)) & 15) != 0)
         return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: xs / wq must be 16-byte aligned");
     if ((long long)batch * ((t + 127) / 128) > 0x7fffffffLL) return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: grid too large");
-    const hipError_t e = mvq::launch_conv_k7_bf16x6(xs, wq, bias, alpha_out, y, batch, cin, t, cout, dil, tvalid, wide, S(stream));
+    const hipError_t e = mvq::launch_conv_k7_bf16x6(xs, wq, bias, alpha_out, y, batch, cin, t, cout, dil, tvalid, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_k7_bf16x6");
 }
 

@@ -14,5 +14,5 @@ hipError_t launch_bf16x3_split(const float* x, void* xs, int batch, int c, int t
 int bf16x6_tile_rows(int cout);      // 128, 96 or 0 (no tile)
 hipError_t launch_bf16x3_pack_k7(const float* w, void* wq, int cout, int cin, hipStream_t s);
 hipError_t launch_conv_k7_bf16x6(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y, int batch, int cin,
-                                 int t, int cout, int dil, int tvalid, int wide, hipStream_t s);
+                                 int t, int cout, int dil, int tvalid, hipStream_t s);
 }  // namespace mvq

@@ -336,10 +336,12 @@ hipError_t launch_bf16x3_pack_k7(const float* w, void* wq, int cout, int cin, hi
     return hipGetLastError();
 }
 
-// wide: 0 = the default tile of the row count (128 x 128 on 2 x 2 waves, or 96 x 128 on 1 x 4 waves for Cout % 128 != 0, two blocks
-// per CU); 1 / 2 = A/B forms of the 128-row tile with 256 columns on 8 waves (ring of six / four)
+// Tile per row count: 128 x 128 on 2 x 2 waves, or 96 x 128 on 1 x 4 waves where 128 does not divide Cout (C = 192); two blocks per
+// CU, weight ring of three.  Measured and not kept (profiles/r04_timing_experiments.json::bf16x6_forms): 128 x 256 tiles on eight
+// waves with a ring of four or six slices -- the same 205-220 TFLOP/s on every layer: the loop is not waiting for its DMA, the chip
+// holds its clock down under the bf16 matrix load (MI355X guide, "clock under load").
 hipError_t launch_conv_k7_bf16x6(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y, int batch, int cin,
-                                 int t, int cout, int dil, int tvalid, int wide, hipStream_t s)
+                                 int t, int cout, int dil, int tvalid, hipStream_t s)
 {
     K7BfArgs a{};
     a.xs = reinterpret_cast<const bf16x8*>(xs); a.wq = reinterpret_cast<const bf16x8*>(wq); a.bias = bias; a.alpha_out = alpha_out; a.y = y;
@@ -350,18 +352,6 @@ hipError_t launch_conv_k7_bf16x6(const void* xs, const void* wq, const float* bi
             case 1: return launch_k7bf<1, 3, 1, 1, 4, 3>(a, s);
             case 3: return launch_k7bf<3, 3, 1, 1, 4, 3>(a, s);
             case 9: return launch_k7bf<9, 3, 1, 1, 4, 3>(a, s);
-        }
-    } else if (bm == 128 && wide == 2) {
-        switch (dil) {
-            case 1: return launch_k7bf<1, 2, 2, 2, 4, 4>(a, s);
-            case 3: return launch_k7bf<3, 2, 2, 2, 4, 4>(a, s);
-            case 9: return launch_k7bf<9, 2, 2, 2, 4, 4>(a, s);
-        }
-    } else if (bm == 128 && wide) {
-        switch (dil) {
-            case 1: return launch_k7bf<1, 2, 2, 2, 4, 6>(a, s);
-            case 3: return launch_k7bf<3, 2, 2, 2, 4, 6>(a, s);
-            case 9: return launch_k7bf<9, 2, 2, 2, 4, 6>(a, s);
         }
     } else if (bm == 128) {
         switch (dil) {

@@ -170,7 +170,8 @@ def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x
 
 # ---- opt-in, NON-PARITY arithmetic mode "bf16x6" (include/mvq.h; csrc/conv_k7_bf16.hip) ------------------------------------------
 # The default ("f32") computes every conv as the exact fp32 fma chain of the arithmetic contract.  set_arith("bf16x6") routes the
-# 7-tap convs of the wide ResidualUnits (C a multiple of 128) through the three-piece bf16 split: fp32-accurate, not bit-identical.
+# 7-tap convs of the wide ResidualUnits (C a multiple of 128, or of 96: C = 192) through the three-piece bf16 split: fp32-accurate,
+# not bit-identical; everything else keeps the exact path.
 _ARITH = "f32"
 
 
@@ -186,7 +187,11 @@ def get_arith() -> str:
 
 
 def bf16x6_eligible(c: int) -> bool:
-    return _ARITH == "bf16x6" and (c % 128 == 0 or c % 96 == 0) and c % 16 == 0
+    if _ARITH != "bf16x6" or c % 16 != 0:
+        return False
+    if os.environ.get("MVQ_BF16X6_NO96") == "1":          # A/B knob: 128-row tiles only
+        return c % 128 == 0
+    return c % 128 == 0 or c % 96 == 0
 
 
 def bf16x3_split(x):
@@ -210,13 +215,11 @@ def pack_conv1d_k7_bf16x3(w):
     return wq
 
 
-def conv1d_k7_bf16x6(xs, wq, batch, cin, t, cout, dil, bias=None, alpha_out=None, tvalid=0, wide=None):
+def conv1d_k7_bf16x6(xs, wq, batch, cin, t, cout, dil, bias=None, alpha_out=None, tvalid=0):
     """y[B, cout, t] = snake_out(conv7_dil(xs) + bias) on the bf16x6 matrix path; xs from bf16x3_split, wq from pack_conv1d_k7_bf16x3."""
     y = torch.empty(batch, cout, t, device=xs.device, dtype=torch.float32)
-    if wide is None:
-        wide = int(os.environ.get("MVQ_BF16X6_WIDE", "0"))
     check(_lib.lib().mvq_conv1d_k7_bf16x6_f32(xs.data_ptr(), wq.data_ptr(), _p(bias), _p(alpha_out), y.data_ptr(), batch, cin, t,
-                                              cout, dil, int(tvalid), int(wide), _stream()), "mvq_conv1d_k7_bf16x6_f32")
+                                              cout, dil, int(tvalid), _stream()), "mvq_conv1d_k7_bf16x6_f32")
     return y
 
 

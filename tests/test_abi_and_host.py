@@ -228,3 +228,19 @@ def test_vpacked_geometry_and_argument_checks():
     assert bad(4, 512, 76, 76, 1024, 3, 1, 1, 1, 0, 10, 76, 76) == -1                                                 # no zero gap for the padding
     assert bad(4, 512, 600, 600, 1024, 16, 8, 1, 4, 0, 10, 608, 76) == -1 and b"null tensor" in lib.mvq_last_error()  # geometry fine
     assert bad(0, 512, 600, 600, 1024, 16, 8, 1, 4, 0, 10, 608, 76) == 0                                              # empty batch
+
+
+def test_arith_mode_switch_is_opt_in_and_validated():
+    """The non-parity "bf16x6" mode (include/mvq.h) is off unless asked for, refuses unknown names, and only claims the wide units."""
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    from multimodal_vqvae_compression_audio_tactile_amd._lib import MvqError
+    assert ops.get_arith() == "f32"
+    assert not any(ops.bf16x6_eligible(c) for c in (64, 96, 128, 192, 256, 768))
+    with pytest.raises(MvqError):
+        ops.set_arith("fp16")
+    ops.set_arith("bf16x6")
+    try:
+        assert [c for c in (64, 96, 100, 128, 192, 256, 384, 512, 768) if ops.bf16x6_eligible(c)] == [96, 128, 192, 256, 384, 512, 768]
+    finally:
+        ops.set_arith("f32")
+    assert ops.get_arith() == "f32"

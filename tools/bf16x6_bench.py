@@ -29,9 +29,7 @@ for name, C, T in (("enc.b2", 256, 3000), ("enc.b3", 512, 600), ("dec.b0", 768, 
         flops = 2.0 * C * C * 7 * T * B
         t_exact = timeit(lambda: ops.conv1d(x, wp, C, 7, bias=bias, dil=dil, pad=3 * dil, alpha_out=alpha))
         t_split = timeit(lambda: ops.bf16x3_split(x))
-        t_n = timeit(lambda: ops.conv1d_k7_bf16x6(xs, wq, B, C, T, C, dil, bias=bias, alpha_out=alpha, wide=0))
-        t_w = timeit(lambda: ops.conv1d_k7_bf16x6(xs, wq, B, C, T, C, dil, bias=bias, alpha_out=alpha, wide=1))
-        t_w4 = timeit(lambda: ops.conv1d_k7_bf16x6(xs, wq, B, C, T, C, dil, bias=bias, alpha_out=alpha, wide=2))
+        t_n = timeit(lambda: ops.conv1d_k7_bf16x6(xs, wq, B, C, T, C, dil, bias=bias, alpha_out=alpha))
         print(f"{name}.k7d{dil}  C {C:4d} T {T:5d}  exact {t_exact:7.3f} ms {flops/t_exact*1e-9:6.1f} TF | split {t_split:6.3f} ms | "
-              f"bf16x6 128-col {t_n:7.3f} ms {flops/t_n*1e-9:6.1f} TF | 256-col ring6 {t_w:7.3f} ms {flops/t_w*1e-9:6.1f} TF | ring4 {t_w4:7.3f} ms {flops/t_w4*1e-9:6.1f} TF", flush=True)
+              f"bf16x6 {t_n:7.3f} ms {flops/t_n*1e-9:6.1f} TF | with the split {flops/(t_n+t_split)*1e-9:6.1f} TF", flush=True)
         del x, xs
