@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 latency section (reference protocol)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline = null)")
-    ap.add_argument("--arith", choices=["f32", "bf16x6"], default="f32",
+    ap.add_argument("--arith", choices=["f32", "bf16x6", "f16x3"], default="f32",
                     help="f32 (default, the headline): the exact fp32 fma chains of the arithmetic contract.  bf16x6: the OPT-IN, "
                          "NON-PARITY mode -- the wide units' 7-tap convs as six bf16 piece products per fp32 product (fp32-accurate, "
                          "not bit-identical to the oracle; a separate line with its own dtype, never the headline)")
@@ -516,7 +516,9 @@ def main():
             traffic = pmc_all.get(name, {}).get("hbm_bytes_per_launch")       # null when this kernel is not in the profile
             # a bf16x6 kernel (opt-in mode only) spends six bf16 MFMA products per algorithmic fp32 product: its ceiling is the dense
             # bf16 MFMA peak / 6, in the same algorithmic TFLOP/s the other kernels are quoted in
-            peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if "bf16x6" in name else FP32_MFMA_PEAK_TFLOPS
+            peak = FP32_MFMA_PEAK_TFLOPS
+            if "bf16x6" in name:                                   # last template argument = pieces per operand: 3 -> six products, 2 -> three
+                peak = BF16_MFMA_PEAK_TFLOPS / (3.0 if name.rstrip(">").endswith(", 2") else 6.0)
             line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak,
                                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                                 "traffic_source": pmc_src if traffic is not None else None,

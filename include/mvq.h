@@ -408,6 +408,21 @@ int mvq_conv1d_k7_pack_bf16x3(const float* w, void* wq, int cout, int cin, void*
 int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y,
                              int batch, int cin, int t, int cout, int dil, int tvalid, void* stream);
 
+/* The same opt-in departure with TWO fp16 pieces per operand and THREE piece products ("f16x3"): half the matrix work of bf16x6.
+ * fp16 has 11 significant bits but a 5-bit exponent, so every ITEM of the activations and the weight tensor are first scaled by
+ * the power of two that puts their largest magnitude into [2^13, 2^14) (exact); the scales are kept as the float bit patterns of
+ * those maxima (xamax[batch], wamax[1], written by the split / pack calls) and undone in the conv's epilogue.  Error per product
+ * <= ~3 x 2^-22 (dropped h1 g1 term + the two representation errors): about twice the rounding error of the exact fp32 chain, i.e.
+ * fp32-class but looser than bf16x6; non-finite inputs are outside its contract.
+ *   mvq_f16x2_split_f32       x[batch, c, t] -> xs (4 bytes per element: [batch][c/8][2 pieces][t][8] fp16), xamax[batch]
+ *   mvq_conv1d_k7_pack_f16x2  w[cout, cin, 7] -> wq (mvq_conv1d_k7_f16x2_packed_bytes), wamax[1]
+ *   mvq_conv1d_k7_f16x3_f32   as mvq_conv1d_k7_bf16x6_f32 */
+int mvq_f16x2_split_f32(const float* x, void* xs, uint32_t* xamax, int batch, int c, int t, void* stream);
+size_t mvq_conv1d_k7_f16x2_packed_bytes(int cout, int cin);
+int mvq_conv1d_k7_pack_f16x2(const float* w, void* wq, uint32_t* wamax, int cout, int cin, void* stream);
+int mvq_conv1d_k7_f16x3_f32(const void* xs, const uint32_t* xamax, const void* wq, const uint32_t* wamax, const float* bias,
+                            const float* alpha_out, float* y, int batch, int cin, int t, int cout, int dil, int tvalid, void* stream);
+
 /* Polyphase sinc resampler: torchaudio.transforms.Resample(orig, new) as the reference
  * calls it on every file (Training/compare_dacvsproposal_5.py:110-113, Evaluation/dac_vcpwq_proposed6_latency.py:151-156).
  * orig/newf are the rates divided by their gcd, kern[newf][ks] the filter bank (ks = 2*width + orig),

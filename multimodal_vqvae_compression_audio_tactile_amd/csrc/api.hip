@@ -279,6 +279,46 @@ int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, 
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_k7_bf16x6");
 }
 
+/* f16x3 form of the opt-in mode (include/mvq.h) */
+int mvq_f16x2_split_f32(const float* x, void* xs, uint32_t* xamax, int batch, int c, int t, void* stream)
+{
+    if (batch < 0 || c <= 0 || t < 0 || c % 8 != 0) return fail(MVQ_EINVAL, "f16x2_split: bad shape B=%d C=%d T=%d (C %% 8 == 0)", batch, c, t);
+    if (batch == 0 || t == 0) return MVQ_OK;
+    if (!x || !xs || !xamax) return fail(MVQ_EINVAL, "f16x2_split: null tensor");
+    if ((reinterpret_cast<uintptr_t>(xs) & 15) != 0) return fail(MVQ_EINVAL, "f16x2_split: xs must be 16-byte aligned");
+    const hipError_t e = mvq::launch_f16x2_split(x, xs, xamax, batch, c, t, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "f16x2_split");
+}
+size_t mvq_conv1d_k7_f16x2_packed_bytes(int cout, int cin)
+{
+    if (cout <= 0 || cin <= 0 || mvq::bf16x6_tile_rows(cout) == 0 || cin % 16 != 0) return 0;
+    return (size_t)cout * cin * 7 * 4;
+}
+int mvq_conv1d_k7_pack_f16x2(const float* w, void* wq, uint32_t* wamax, int cout, int cin, void* stream)
+{
+    if (cout <= 0 || cin <= 0 || mvq::bf16x6_tile_rows(cout) == 0 || cin % 16 != 0)
+        return fail(MVQ_EINVAL, "conv1d_k7_pack_f16x2: Cout %d must be a multiple of 128 or 96 and Cin %d of 16", cout, cin);
+    if (!w || !wq || !wamax) return fail(MVQ_EINVAL, "conv1d_k7_pack_f16x2: null tensor");
+    if ((reinterpret_cast<uintptr_t>(wq) & 15) != 0) return fail(MVQ_EINVAL, "conv1d_k7_pack_f16x2: wq must be 16-byte aligned");
+    const hipError_t e = mvq::launch_f16x2_pack_k7(w, wq, wamax, cout, cin, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_k7_pack_f16x2");
+}
+int mvq_conv1d_k7_f16x3_f32(const void* xs, const uint32_t* xamax, const void* wq, const uint32_t* wamax, const float* bias,
+                            const float* alpha_out, float* y, int batch, int cin, int t, int cout, int dil, int tvalid, void* stream)
+{
+    if (batch < 0 || cin <= 0 || cout <= 0 || t < 0 || mvq::bf16x6_tile_rows(cout) == 0 || cin % 16 != 0)
+        return fail(MVQ_EINVAL, "conv1d_k7_f16x3: bad shape B=%d Cin=%d T=%d Cout=%d (Cout %% 128 or 96, Cin %% 16)", batch, cin, t, cout);
+    if (dil != 1 && dil != 3 && dil != 9) return fail(MVQ_EINVAL, "conv1d_k7_f16x3: dilation %d not in {1, 3, 9}", dil);
+    if (tvalid < 0 || tvalid > t) return fail(MVQ_EINVAL, "conv1d_k7_f16x3: tvalid %d outside [0, %d]", tvalid, t);
+    if (batch == 0 || t == 0) return MVQ_OK;
+    if (!xs || !wq || !y || !xamax || !wamax) return fail(MVQ_EINVAL, "conv1d_k7_f16x3: null tensor");
+    if (((reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(wq)) & 15) != 0)
+        return fail(MVQ_EINVAL, "conv1d_k7_f16x3: xs / wq must be 16-byte aligned");
+    if ((long long)batch * ((t + 127) / 128) > 0x7fffffffLL) return fail(MVQ_EINVAL, "conv1d_k7_f16x3: grid too large");
+    const hipError_t e = mvq::launch_conv_k7_f16x3(xs, xamax, wq, wamax, bias, alpha_out, y, batch, cin, t, cout, dil, tvalid, S(stream));
+    return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_k7_f16x3");
+}
+
 /* which kernel instantiation mvq_conv1d_f32 / mvq_conv_transpose1d_f32 launches for a shape (profiling aid):
  * runs the real dispatch in "name mode" */
 int mvq_conv_kernel_name(int batch, int cin, int cout, int ks, int stride, int dil, int transposed, int tin, char* buf, int len)

@@ -15,4 +15,8 @@ int bf16x6_tile_rows(int cout);      // 128, 96 or 0 (no tile)
 hipError_t launch_bf16x3_pack_k7(const float* w, void* wq, int cout, int cin, hipStream_t s);
 hipError_t launch_conv_k7_bf16x6(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y, int batch, int cin,
                                  int t, int cout, int dil, int tvalid, hipStream_t s);
+hipError_t launch_f16x2_split(const float* x, void* xs, unsigned* xamax, int batch, int c, int t, hipStream_t s);
+hipError_t launch_f16x2_pack_k7(const float* w, void* wq, unsigned* wamax, int cout, int cin, hipStream_t s);
+hipError_t launch_conv_k7_f16x3(const void* xs, const unsigned* xamax, const void* wq, const unsigned* wamax, const float* bias,
+                                const float* alpha_out, float* y, int batch, int cin, int t, int cout, int dil, int tvalid, hipStream_t s);
 }  // namespace mvq

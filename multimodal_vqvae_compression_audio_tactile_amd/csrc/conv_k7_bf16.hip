@@ -24,6 +24,7 @@
 namespace mvq {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16b __attribute__((ext_vector_type(16)));
 
 // ---- operand preparation ------------------------------------------------------------------------------------------------------
@@ -86,6 +87,116 @@ __global__ void bf16x3_pack_k7_kernel(const float* __restrict__ w, bf16x8* __res
     dst[0] = q0; dst[(size_t)2 * BM] = q1; dst[(size_t)4 * BM] = q2;
 }
 
+// ---- f16x3 form: two fp16 pieces under a power-of-two scale ------------------------------------------------------------------------
+// fp16 keeps 11 significant bits but only 5 exponent bits, so a tensor is first scaled by the power of two that puts its largest
+// magnitude into [2^13, 2^14) (exact; well inside the fp16 range, 2^16): a = (h0 + h1) / S with h0 = rne16(a S), h1 = rne16(a S - h0),
+// |a S - h0 - h1| <= max(2^-22 |a S|, 2^-25) -- 22 significant bits for every element within 2^17 of the maximum, an absolute error
+// of 2^-39 of the maximum below that.  One scale per ITEM for the activations (a per-position scale would not factor out of a
+// 7-tap sum), one per tensor for the weights; the conv's epilogue multiplies by the two inverse scales (exact).
+__device__ __host__ __forceinline__ int f16_scale_exp(unsigned amax_bits)
+{
+    const int e = (int)((amax_bits >> 23) & 0xff);                 // biased exponent of the maximum (sign bit is clear)
+    if (e == 0 || e == 0xff) return 0;                              // zero / denormal / non-finite maximum: no scaling
+    return 13 - (e - 127);                                          // S = 2^this
+}
+__device__ __forceinline__ float f16_pow2(int k)
+{
+    k = k < -126 ? -126 : (k > 127 ? 127 : k);
+    return __uint_as_float((unsigned)(k + 127) << 23);
+}
+__device__ __forceinline__ float f16_scale(unsigned amax_bits) { return f16_pow2(f16_scale_exp(amax_bits)); }
+__device__ __forceinline__ float f16_inv_scale(unsigned amax_bits) { return f16_pow2(-f16_scale_exp(amax_bits)); }
+
+// amax[item] = max |x| over the item's `per_item` elements, as float bits (non-negative floats order like unsigned integers);
+// the caller zeroes amax first.  grid (blocks per item, items).
+__global__ void f16_amax_kernel(const float* __restrict__ x, unsigned* __restrict__ amax, size_t per_item)
+{
+    const float* src = x + (size_t)blockIdx.y * per_item;
+    unsigned m = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((per_item & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {       // 16-byte loads, four in flight per thread
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        const size_t n4 = per_item >> 2;
+        size_t i = i0;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const uint4 a = s4[i], b = s4[i + stride], c = s4[i + 2 * stride], d = s4[i + 3 * stride];
+            unsigned q;
+            q = a.x & 0x7fffffffu; m = q > m ? q : m; q = a.y & 0x7fffffffu; m = q > m ? q : m; q = a.z & 0x7fffffffu; m = q > m ? q : m; q = a.w & 0x7fffffffu; m = q > m ? q : m;
+            q = b.x & 0x7fffffffu; m = q > m ? q : m; q = b.y & 0x7fffffffu; m = q > m ? q : m; q = b.z & 0x7fffffffu; m = q > m ? q : m; q = b.w & 0x7fffffffu; m = q > m ? q : m;
+            q = c.x & 0x7fffffffu; m = q > m ? q : m; q = c.y & 0x7fffffffu; m = q > m ? q : m; q = c.z & 0x7fffffffu; m = q > m ? q : m; q = c.w & 0x7fffffffu; m = q > m ? q : m;
+            q = d.x & 0x7fffffffu; m = q > m ? q : m; q = d.y & 0x7fffffffu; m = q > m ? q : m; q = d.z & 0x7fffffffu; m = q > m ? q : m; q = d.w & 0x7fffffffu; m = q > m ? q : m;
+        }
+        for (; i < n4; i += stride) {
+            const uint4 a = s4[i];
+            unsigned q;
+            q = a.x & 0x7fffffffu; m = q > m ? q : m; q = a.y & 0x7fffffffu; m = q > m ? q : m; q = a.z & 0x7fffffffu; m = q > m ? q : m; q = a.w & 0x7fffffffu; m = q > m ? q : m;
+        }
+    } else {
+        for (size_t i = i0; i < per_item; i += stride) {
+            const unsigned u = __float_as_uint(src[i]) & 0x7fffffffu;
+            m = u > m ? u : m;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned v = __shfl_xor(m, o); m = v > m ? v : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(amax + blockIdx.y, m);
+}
+
+__device__ __forceinline__ void split2h(float a, float S, _Float16& p0, _Float16& p1)
+{
+    const float as = a * S;                   // exact (power of two) unless it leaves the fp32 range
+    p0 = (_Float16)as;
+    p1 = (_Float16)(as - (float)p0);          // the subtraction is exact
+}
+
+// x[B][C][T] fp32 -> xs[B][C/8][2][T][8] fp16 under the item's scale
+__global__ void f16x2_split_kernel(const float* __restrict__ x, f16x8* __restrict__ xs, const unsigned* __restrict__ amax, int C, int T, size_t total)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int t = (int)(gid % (size_t)T);
+    const size_t bo = gid / (size_t)T;               // item * (C/8) + octet
+    const float S = f16_scale(amax[bo / (size_t)(C / 8)]);
+    const float* src = x + bo * 8 * (size_t)T + t;
+    f16x8 q0, q1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        _Float16 a, b;
+        split2h(src[(size_t)j * T], S, a, b);
+        q0[j] = a; q1[j] = b;
+    }
+    f16x8* dst = xs + bo * 2 * (size_t)T + t;
+    dst[0] = q0; dst[(size_t)T] = q1;
+}
+
+// w[Cout][Cin][7] fp32 -> wq [Cout/BM][Cin/16][7][2 pieces][2 octets][BM][8] fp16 under the tensor's scale
+__global__ void f16x2_pack_k7_kernel(const float* __restrict__ w, f16x8* __restrict__ wq, const unsigned* __restrict__ amax, int Cout, int Cin,
+                                     int BM, size_t total)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    size_t r = gid;
+    const int m = (int)(r % (size_t)BM); r /= (size_t)BM;
+    const int h = (int)(r % 2); r /= 2;
+    const int tap = (int)(r % 7); r /= 7;
+    const int ncb = Cin / 16;
+    const int cb = (int)(r % (size_t)ncb);
+    const int mt = (int)(r / (size_t)ncb);
+    const int co = mt * BM + m;
+    const float S = f16_scale(amax[0]);
+    f16x8 q0, q1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = cb * 16 + h * 8 + j;
+        _Float16 a, b;
+        split2h(w[((size_t)co * Cin + ci) * 7 + tap], S, a, b);
+        q0[j] = a; q1[j] = b;
+    }
+    const size_t slice = ((size_t)mt * ncb + cb) * 7 + tap;
+    f16x8* dst = wq + slice * (size_t)(4 * BM) + (size_t)h * BM + m;
+    dst[0] = q0; dst[(size_t)2 * BM] = q1;
+}
+
 // ---- the conv -----------------------------------------------------------------------------------------------------------------
 struct K7BfArgs {
     const bf16x8* xs;       // split activations (already carry the input Snake)
@@ -96,16 +207,20 @@ struct K7BfArgs {
     int B, Cin, Cout, T;
     int n_tiles;            // column tiles per item
     int tvalid;             // > 0: columns >= tvalid are written as zeros (zero-padded rows, include/mvq.h)
+    // f16x3 form only: |x| maximum of every item / of the weight tensor as float bit patterns (the power-of-two scales the split
+    // applied follow from them: f16_scale_exp); null in the bf16x6 form
+    const unsigned* xamax;
+    const unsigned* wamax;
 };
 
-template <int DIL, int MT, int NT, int WM, int WN, int NST>
+template <int DIL, int MT, int NT, int WM, int WN, int NST, int NP>
 struct K7BfCfg {
     static constexpr int NW = WM * WN, NTHR = 64 * NW;
     static constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     static constexpr int XT = BN + 6 * DIL;                 // activation positions a tile needs
-    static constexpr int XPIECES = 6 * XT;                  // 16-byte pieces of one channel block's tile: [piece][octet][position]
+    static constexpr int XPIECES = 2 * NP * XT;             // 16-byte pieces of one channel block's tile: [piece][octet][position]
     static constexpr int XBYTES = XPIECES * 16;
-    static constexpr int WPIECES = 3 * 2 * BM;              // one (channel block, tap) weight slice
+    static constexpr int WPIECES = NP * 2 * BM;             // one (channel block, tap) weight slice
     static constexpr int WBYTES = WPIECES * 16;
     static constexpr int NUX = (XPIECES + NTHR - 1) / NTHR; // DMA instructions per wave for an activation tile (the last may be partial)
     static constexpr int NUW = (WPIECES + NTHR - 1) / NTHR;
@@ -132,11 +247,12 @@ __device__ __forceinline__ void vm_wait_dyn(int n)
     }
 }
 
-template <int DIL, int MT, int NT, int WM, int WN, int NST>
+template <int DIL, int MT, int NT, int WM, int WN, int NST, int NP>
 __global__ __attribute__((amdgpu_flat_work_group_size(1, 64 * WM * WN), amdgpu_waves_per_eu(2)))
 void conv_k7_bf16x6_kernel(const K7BfArgs a)
 {
-    using C = K7BfCfg<DIL, MT, NT, WM, WN, NST>;
+    using C = K7BfCfg<DIL, MT, NT, WM, WN, NST, NP>;
+    static_assert(NP == 3 || NP == 2, "three bf16 pieces (six products) or two fp16 pieces (three products)");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -162,11 +278,11 @@ void conv_k7_bf16x6_kernel(const K7BfArgs a)
         xlive[u] = q < C::XPIECES;
         const int qq = xlive[u] ? q : C::XPIECES - 1;
         const int ph = qq / C::XT, tt = qq - ph * C::XT;
-        const int p = ph >> 1, o = ph & 1;
+        const int p = ph >> 1, o = ph & 1;                     // piece, octet of the channel block
         const int t = t0 + tt;
         const bool ok = t >= 0 && t < a.T;
-        xsrc[u] = ok ? a.xs + (((size_t)b * (a.Cin / 8) + o) * 3 + p) * T + t : reinterpret_cast<const bf16x8*>(g_zero16);
-        xstep[u] = ok ? (long long)(2 * 3) * (long long)T : 0;
+        xsrc[u] = ok ? a.xs + (((size_t)b * (a.Cin / 8) + o) * NP + p) * T + t : reinterpret_cast<const bf16x8*>(g_zero16);
+        xstep[u] = ok ? (long long)(2 * NP) * (long long)T : 0;
     }
     // weight pieces: slice s of this row tile starts at wq + (mt * n_steps + s) * WPIECES
     const bf16x8* wsrc[C::NUW];
@@ -247,28 +363,39 @@ void conv_k7_bf16x6_kernel(const K7BfArgs a)
             if (s + NST - 1 < n_steps) dma_w(wst >= 1 ? wst - 1 : NST - 1);   // (s + NST - 1) % NST
             if (tap == 1 && more_cb) dma_x((cb + 1) & 1);
             const bf16x8* const wb = wl + wst * C::WPIECES + a_frag;
-            bf16x8 af[MT][3], bq[NT][3];
+            bf16x8 af[MT][NP], bq[NT][NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) af[i][p] = wb[p * 2 * C::BM + i * 32];
 #pragma unroll
                 for (int j = 0; j < NT; ++j) bq[j][p] = xb[p * 2 * C::XT + j * 32 + tap * DIL];
             }
-            // six piece products per (i, j), smallest first: (w2,x0) (w0,x2) (w1,x1) (w1,x0) (w0,x1) (w0,x0); the four accumulators
-            // rotate inside each product, so a dependent MFMA on one accumulator is four issues (128 cycles) behind its producer
-            constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+            // piece products per (i, j), smallest first -- bf16x6: (w2,x0) (w0,x2) (w1,x1) (w1,x0) (w0,x1) (w0,x0); f16x3: (w1,x0) (w0,x1)
+            // (w0,x0).  The accumulators rotate inside each product, so a dependent MFMA on one accumulator is MT*NT issues behind its
+            // producer.
+            constexpr int NPROD = NP == 3 ? 6 : 3;
+            constexpr int PW6[6] = {2, 0, 1, 1, 0, 0}, PX6[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int PW3[3] = {1, 0, 0}, PX3[3] = {0, 1, 0};
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
+            for (int k = 0; k < NPROD; ++k)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PW[k]], bq[j][PX[k]], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) {
+                        if constexpr (NP == 3)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PW6[k]], bq[j][PX6[k]], acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][PW3[k]]),
+                                                                               __builtin_bit_cast(f16x8, bq[j][PX3[k]]), acc[i][j], 0, 0, 0);
+                    }
             wst = wst == NST - 1 ? 0 : wst + 1;
         }
     }
 
+    // f16x3: undo the two power-of-two scales of the split (exact)
+    float oscale = 1.0f;
+    if constexpr (NP == 2) oscale = f16_inv_scale(a.xamax[b]) * f16_inv_scale(a.wamax[0]);
     // ---- epilogue straight from the accumulators: register r of a 32x32 tile is row (r & 3) + 8 (r >> 2) + 4 h, the lane is the
     // column, so one store instruction writes two 128-byte row segments.  bias, then the Snake (the same det_snake as the exact path).
 #pragma unroll
@@ -283,7 +410,9 @@ void conv_k7_bf16x6_kernel(const K7BfArgs a)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = n0 + wn * (32 * NT) + j * 32 + l31;
-                float v = acc[i][j][r] + bv;
+                float v = acc[i][j][r];
+                if constexpr (NP == 2) v = v * oscale;
+                v = v + bv;
                 if (a.alpha_out) v = det_snake(v, al, inv);
                 if (a.tvalid > 0 && n >= a.tvalid) v = 0.0f;
                 if (n < a.T) yrow[n] = v;
@@ -291,14 +420,14 @@ void conv_k7_bf16x6_kernel(const K7BfArgs a)
         }
 }
 
-template <int DIL, int MT, int NT, int WM, int WN, int NST>
+template <int DIL, int MT, int NT, int WM, int WN, int NST, int NP>
 static hipError_t launch_k7bf(const K7BfArgs& a_in, hipStream_t s)
 {
-    using C = K7BfCfg<DIL, MT, NT, WM, WN, NST>;
+    using C = K7BfCfg<DIL, MT, NT, WM, WN, NST, NP>;
     if (a_in.Cout % C::BM != 0) return hipErrorInvalidValue;
     K7BfArgs a = a_in;
     a.n_tiles = (a.T + C::BN - 1) / C::BN;
-    auto kern = conv_k7_bf16x6_kernel<DIL, MT, NT, WM, WN, NST>;
+    auto kern = conv_k7_bf16x6_kernel<DIL, MT, NT, WM, WN, NST, NP>;
     {
         static BigLdsOptIn opt;
         const hipError_t e = opt.ensure(reinterpret_cast<const void*>(kern));
@@ -307,7 +436,7 @@ static hipError_t launch_k7bf(const K7BfArgs& a_in, hipStream_t s)
     int pi = -1;
     if (prof_enabled()) {
         char nm[96];
-        snprintf(nm, sizeof(nm), "conv_k7_bf16x6_kernel<%d, %d, %d, %d, %d, %d>", DIL, MT, NT, WM, WN, NST);
+        snprintf(nm, sizeof(nm), "conv_k7_bf16x6_kernel<%d, %d, %d, %d, %d, %d, %d>", DIL, MT, NT, WM, WN, NST, NP);
         const int cols = a.tvalid > 0 ? a.tvalid : a.T;
         pi = prof_begin(nm, 2.0 * a.Cin * 7.0 * a.Cout * (double)cols * a.B, s);
     }
@@ -349,15 +478,67 @@ hipError_t launch_conv_k7_bf16x6(const void* xs, const void* wq, const float* bi
     const int bm = bf16x6_tile_rows(cout);
     if (bm == 96) {
         switch (dil) {
-            case 1: return launch_k7bf<1, 3, 1, 1, 4, 3>(a, s);
-            case 3: return launch_k7bf<3, 3, 1, 1, 4, 3>(a, s);
-            case 9: return launch_k7bf<9, 3, 1, 1, 4, 3>(a, s);
+            case 1: return launch_k7bf<1, 3, 1, 1, 4, 3, 3>(a, s);
+            case 3: return launch_k7bf<3, 3, 1, 1, 4, 3, 3>(a, s);
+            case 9: return launch_k7bf<9, 3, 1, 1, 4, 3, 3>(a, s);
         }
     } else if (bm == 128) {
         switch (dil) {
-            case 1: return launch_k7bf<1, 2, 2, 2, 2, 3>(a, s);
-            case 3: return launch_k7bf<3, 2, 2, 2, 2, 3>(a, s);
-            case 9: return launch_k7bf<9, 2, 2, 2, 2, 3>(a, s);
+            case 1: return launch_k7bf<1, 2, 2, 2, 2, 3, 3>(a, s);
+            case 3: return launch_k7bf<3, 2, 2, 2, 2, 3, 3>(a, s);
+            case 9: return launch_k7bf<9, 2, 2, 2, 2, 3, 3>(a, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- f16x3 form -----------------------------------------------------------------------------------------------------------------
+static hipError_t launch_f16_amax(const float* x, unsigned* amax, int items, size_t per_item, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(amax, 0, sizeof(unsigned) * (size_t)items, s);
+    if (e != hipSuccess) return e;
+    unsigned bx = (unsigned)((per_item + 256 * 64 - 1) / (256 * 64));        // ~64 elements per thread
+    bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+    hipLaunchKernelGGL(f16_amax_kernel, dim3(bx, (unsigned)items), dim3(256), 0, s, x, amax, per_item);
+    return hipGetLastError();
+}
+hipError_t launch_f16x2_split(const float* x, void* xs, unsigned* xamax, int batch, int c, int t, hipStream_t s)
+{
+    const size_t total = (size_t)batch * (c / 8) * t;
+    if (total == 0) return hipSuccess;
+    const hipError_t e = launch_f16_amax(x, xamax, batch, (size_t)c * t, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(f16x2_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, reinterpret_cast<f16x8*>(xs), xamax, c, t, total);
+    return hipGetLastError();
+}
+hipError_t launch_f16x2_pack_k7(const float* w, void* wq, unsigned* wamax, int cout, int cin, hipStream_t s)
+{
+    const int bm = bf16x6_tile_rows(cout);
+    if (bm == 0) return hipErrorInvalidValue;
+    const hipError_t e = launch_f16_amax(w, wamax, 1, (size_t)cout * cin * 7, s);
+    if (e != hipSuccess) return e;
+    const size_t total = (size_t)(cout / bm) * (cin / 16) * 7 * 2 * bm;
+    hipLaunchKernelGGL(f16x2_pack_k7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<f16x8*>(wq), wamax, cout, cin, bm, total);
+    return hipGetLastError();
+}
+hipError_t launch_conv_k7_f16x3(const void* xs, const unsigned* xamax, const void* wq, const unsigned* wamax, const float* bias,
+                                const float* alpha_out, float* y, int batch, int cin, int t, int cout, int dil, int tvalid, hipStream_t s)
+{
+    K7BfArgs a{};
+    a.xs = reinterpret_cast<const bf16x8*>(xs); a.wq = reinterpret_cast<const bf16x8*>(wq); a.bias = bias; a.alpha_out = alpha_out; a.y = y;
+    a.B = batch; a.Cin = cin; a.Cout = cout; a.T = t; a.tvalid = tvalid; a.xamax = xamax; a.wamax = wamax;
+    const int bm = bf16x6_tile_rows(cout);
+    if (bm == 96) {
+        switch (dil) {
+            case 1: return launch_k7bf<1, 3, 1, 1, 4, 3, 2>(a, s);
+            case 3: return launch_k7bf<3, 3, 1, 1, 4, 3, 2>(a, s);
+            case 9: return launch_k7bf<9, 3, 1, 1, 4, 3, 2>(a, s);
+        }
+    } else if (bm == 128) {
+        switch (dil) {
+            case 1: return launch_k7bf<1, 2, 2, 2, 2, 3, 2>(a, s);
+            case 3: return launch_k7bf<3, 2, 2, 2, 2, 3, 2>(a, s);
+            case 9: return launch_k7bf<9, 2, 2, 2, 2, 3, 2>(a, s);
         }
     }
     return hipErrorInvalidValue;

@@ -102,6 +102,12 @@ class WNConv1d(_WNKeys, nn.Module):
             self._packed_bf = _Packed()
         return self._packed_bf.get((self.weight_g, self.weight_v), lambda: ops.pack_conv1d_k7_bf16x3(self.folded_weight()))
 
+    def packed_f16x2(self):
+        """(two-piece fp16 image, |w| maximum) of the folded 7-tap weights: the opt-in, non-parity "f16x3" mode only."""
+        if not hasattr(self, "_packed_f16"):
+            self._packed_f16 = _Packed()
+        return self._packed_f16.get((self.weight_g, self.weight_v), lambda: ops.pack_conv1d_k7_f16x2(self.folded_weight()))
+
     def packed_dgrad(self) -> torch.Tensor:
         if not hasattr(self, "_packed_dg"):
             self._packed_dg = _Packed()
@@ -190,7 +196,9 @@ class ResidualUnit(nn.Module):
     def run(self, x, alpha_next=None, x_snaked=None, alpha_dual=None, tvalid=0):
         c7, c1 = self.block[1], self.block[3]
         # opt-in "bf16x6" mode (ops.set_arith; NOT bit-identical to the oracle): the 7-tap conv of a wide unit on the bf16 matrix cores
-        w7q = c7.packed_bf16x3() if (x_snaked is not None and ops.bf16x6_eligible(c7.cin)) else None
+        w7q = None
+        if x_snaked is not None and ops.bf16x6_eligible(c7.cin):
+            w7q = c7.packed_f16x2() if ops.get_arith() == "f16x3" else c7.packed_bf16x3()
         return ops.residual_unit(x, c7.packed(), c7.bias.detach(), self.block[0].flat(), self.block[2].flat(),
                                  c1.packed(), c1.bias.detach(), c7.dilation, alpha_next=alpha_next, x_snaked=x_snaked,
                                  alpha_dual=alpha_dual, tvalid=tvalid, w7q=w7q)

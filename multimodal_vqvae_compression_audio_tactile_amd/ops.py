@@ -159,7 +159,10 @@ def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x
     B, C, T = x.shape
     if _lib.lib().mvq_residual_unit_scratch_floats(B, C, T, dil) == 0:
         return residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next, alpha_dual, tvalid, x_snaked)
-    if x_snaked is not None and w7q is not None:      # opt-in bf16x6 mode (set_arith): non-parity, fp32-accurate
+    if x_snaked is not None and w7q is not None and _ARITH == "f16x3":     # opt-in modes (set_arith): non-parity, fp32-class
+        xs, xamax = f16x2_split(x_snaked)
+        h = conv1d_k7_f16x3(xs, xamax, w7q[0], w7q[1], B, C, T, C, dil, bias=b7, alpha_out=alpha_b, tvalid=tvalid)
+    elif x_snaked is not None and w7q is not None:
         h = conv1d_k7_bf16x6(bf16x3_split(x_snaked), w7q, B, C, T, C, dil, bias=b7, alpha_out=alpha_b, tvalid=tvalid)
     elif x_snaked is not None:
         h = conv1d(x_snaked, w7p, C, 7, bias=b7, dil=dil, pad=3 * dil, alpha_out=alpha_b, tvalid=tvalid)
@@ -177,8 +180,8 @@ _ARITH = "f32"
 
 def set_arith(mode: str) -> None:
     global _ARITH
-    if mode not in ("f32", "bf16x6"):
-        raise MvqError(f"set_arith: unknown mode {mode!r} (f32 | bf16x6)")
+    if mode not in ("f32", "bf16x6", "f16x3"):
+        raise MvqError(f"set_arith: unknown mode {mode!r} (f32 | bf16x6 | f16x3)")
     _ARITH = mode
 
 
@@ -187,7 +190,7 @@ def get_arith() -> str:
 
 
 def bf16x6_eligible(c: int) -> bool:
-    if _ARITH != "bf16x6" or c % 16 != 0:
+    if _ARITH not in ("bf16x6", "f16x3") or c % 16 != 0:
         return False
     if os.environ.get("MVQ_BF16X6_NO96") == "1":          # A/B knob: 128-row tiles only
         return c % 128 == 0
@@ -220,6 +223,37 @@ def conv1d_k7_bf16x6(xs, wq, batch, cin, t, cout, dil, bias=None, alpha_out=None
     y = torch.empty(batch, cout, t, device=xs.device, dtype=torch.float32)
     check(_lib.lib().mvq_conv1d_k7_bf16x6_f32(xs.data_ptr(), wq.data_ptr(), _p(bias), _p(alpha_out), y.data_ptr(), batch, cin, t,
                                               cout, dil, int(tvalid), _stream()), "mvq_conv1d_k7_bf16x6_f32")
+    return y
+
+
+def f16x2_split(x):
+    """x[B, C, T] fp32 -> (two-piece fp16 image [B][C/8][2][T][8] as a flat int16 tensor, per-item |x| maxima as int32 bit patterns)."""
+    x = _dev(x, "x")
+    B, C, T = x.shape
+    xs = torch.empty(B * C * T * 2, device=x.device, dtype=torch.int16)
+    xamax = torch.empty(max(B, 1), device=x.device, dtype=torch.int32)
+    check(_lib.lib().mvq_f16x2_split_f32(x.data_ptr(), xs.data_ptr(), xamax.data_ptr(), B, C, T, _stream()), "mvq_f16x2_split_f32")
+    return xs, xamax
+
+
+def pack_conv1d_k7_f16x2(w):
+    """Folded weights w[Cout, Cin, 7] fp32 -> (packed two-piece fp16 image, the tensor's |w| maximum as an int32 bit pattern)."""
+    w = _dev(w, "w").contiguous()
+    cout, cin, ks = w.shape
+    n = _lib.lib().mvq_conv1d_k7_f16x2_packed_bytes(cout, cin)
+    if ks != 7 or n == 0:
+        raise MvqError(f"pack_conv1d_k7_f16x2: needs [Cout % 128 == 0 or % 96 == 0, Cin % 16 == 0, 7], got {tuple(w.shape)}")
+    wq = torch.empty(n // 2, device=w.device, dtype=torch.int16)
+    wamax = torch.empty(1, device=w.device, dtype=torch.int32)
+    check(_lib.lib().mvq_conv1d_k7_pack_f16x2(w.data_ptr(), wq.data_ptr(), wamax.data_ptr(), cout, cin, _stream()), "mvq_conv1d_k7_pack_f16x2")
+    return wq, wamax
+
+
+def conv1d_k7_f16x3(xs, xamax, wq, wamax, batch, cin, t, cout, dil, bias=None, alpha_out=None, tvalid=0):
+    """y[B, cout, t] = snake_out(conv7_dil(xs) + bias) with two fp16 pieces per operand (three piece products)."""
+    y = torch.empty(batch, cout, t, device=xs.device, dtype=torch.float32)
+    check(_lib.lib().mvq_conv1d_k7_f16x3_f32(xs.data_ptr(), xamax.data_ptr(), wq.data_ptr(), wamax.data_ptr(), _p(bias), _p(alpha_out),
+                                             y.data_ptr(), batch, cin, t, cout, dil, int(tvalid), _stream()), "mvq_conv1d_k7_f16x3_f32")
     return y
 
 

@@ -238,9 +238,10 @@ def test_arith_mode_switch_is_opt_in_and_validated():
     assert not any(ops.bf16x6_eligible(c) for c in (64, 96, 128, 192, 256, 768))
     with pytest.raises(MvqError):
         ops.set_arith("fp16")
-    ops.set_arith("bf16x6")
-    try:
+    for mode in ("bf16x6", "f16x3"):
+      ops.set_arith(mode)
+      try:
         assert [c for c in (64, 96, 100, 128, 192, 256, 384, 512, 768) if ops.bf16x6_eligible(c)] == [96, 128, 192, 256, 384, 512, 768]
-    finally:
+      finally:
         ops.set_arith("f32")
     assert ops.get_arith() == "f32"

@@ -76,6 +76,64 @@ def test_conv_k7_bf16x6_is_fp32_accurate(C, T, dil, tvalid, dev):
     assert e_new.pow(2).mean().sqrt().item() <= 2.0 * e_old.pow(2).mean().sqrt().item() + 1e-9
 
 
+def _f16_scale(amax):
+    """power of two that puts amax into [2^13, 2^14) (csrc/conv_k7_bf16.hip::f16_scale_exp)"""
+    import numpy as np
+    if amax == 0 or not np.isfinite(amax) or amax < 2.0 ** -126:
+        return 1.0
+    return 2.0 ** (13 - int(np.floor(np.log2(amax))))
+
+
+def test_f16_split_is_bit_exact(dev):
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    torch.manual_seed(5)
+    B, C, T = 4, 24, 91
+    x = torch.randn(B, C, T, device=dev) * torch.tensor([1e-3, 1.0, 37.0, 0.0], device=dev)[:, None, None]
+    x[1, 3, 7] = 250.0
+    xs, xamax = ops.f16x2_split(x)
+    xs = xs.view(torch.float16).reshape(B, C // 8, 2, T, 8)
+    am = x.abs().flatten(1).amax(1)
+    assert torch.equal(xamax.view(torch.float32), am)
+    for b in range(B):
+        S = _f16_scale(float(am[b]))
+        a = x[b] * S
+        h0 = a.half(); h1 = (a - h0.float()).half()
+        for p, h in enumerate((h0, h1)):
+            want = h.reshape(C // 8, 8, T).permute(0, 2, 1).contiguous()
+            assert (xs[b, :, p].float() == want.float()).all(), (b, p)        # value equality: a residual of an exact zero may carry either sign
+        back = (h0.float() + h1.float()) / S
+        assert ((back - x[b]).abs() <= torch.maximum(x[b].abs() * 2.0 ** -21, am[b] * 2.0 ** -37)).all()
+
+
+@pytest.mark.parametrize("C,T,dil,tvalid", [(128, 300, 1, 0), (256, 601, 3, 0), (384, 260, 9, 259), (192, 516, 9, 515)])
+@pytest.mark.parametrize("gain", [1.0, 3.0e3, 2.0e-4])
+def test_conv_k7_f16x3_is_fp32_class(C, T, dil, tvalid, gain, dev):
+    """Two fp16 pieces, three products: ~2x the rounding error of the exact chain at any input scale (the per-item / per-tensor
+    power-of-two scaling keeps the pieces inside the fp16 range)."""
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    torch.manual_seed(C + T + dil)
+    B = 3
+    x = torch.randn(B, C, T, device=dev) * gain * torch.tensor([1.0, 0.01, 30.0], device=dev)[:, None, None]
+    if tvalid:
+        x[..., tvalid:] = 0.0
+    w = torch.randn(C, C, 7, device=dev) / (math.sqrt(7 * C) * gain)
+    bias = torch.randn(C, device=dev)
+    xs, xamax = ops.f16x2_split(x)
+    wq, wamax = ops.pack_conv1d_k7_f16x2(w)
+    y = ops.conv1d_k7_f16x3(xs, xamax, wq, wamax, B, C, T, C, dil, bias=bias, tvalid=tvalid)
+    exact = ops.conv1d(x, ops.pack_conv1d(w), C, 7, bias=bias, dil=dil, pad=3 * dil, tvalid=tvalid)
+    truth = torch.nn.functional.conv1d(x.double(), w.double(), bias.double(), padding=3 * dil, dilation=dil)
+    if tvalid:
+        truth[..., tvalid:] = 0.0
+        assert (y[..., tvalid:] == 0).all()
+    assert torch.isfinite(y).all()
+    for b in range(B):                                            # per item: its own scale
+        e_new = (y[b].double() - truth[b]).abs(); e_old = (exact[b].double() - truth[b]).abs()
+        rms = lambda e: e.pow(2).mean().sqrt().item()
+        assert rms(e_new) <= 4.0 * rms(e_old) + 1e-12, (b, rms(e_new), rms(e_old))
+        assert e_new.max().item() <= 8.0 * e_old.max().item() + 1e-12, (b, e_new.max().item(), e_old.max().item())
+
+
 def test_conv_k7_bf16x6_rejects_bad_shapes(dev):
     from multimodal_vqvae_compression_audio_tactile_amd import ops
     from multimodal_vqvae_compression_audio_tactile_amd._lib import MvqError
@@ -88,8 +146,9 @@ def test_conv_k7_bf16x6_rejects_bad_shapes(dev):
         ops.conv1d_k7_bf16x6(xs, wq, 1, 128, 16, 128, 2)                          # dilation
 
 
+@pytest.mark.parametrize("mode", ["bf16x6", "f16x3"])
 @pytest.mark.parametrize("name", ["b8_k512", "b3_k128_use2"])
-def test_g4_fixture_in_bf16x6_mode(name, dev):
+def test_g4_fixture_in_bf16x6_mode(name, mode, dev):
     """The whole ProposedEval chain in the opt-in mode against the fixture from the REFERENCE classes (G4): every index mismatch is
     classified by the fixture's stored top-1 / top-2 margin (golden_inputs.check_indices asserts that a first flip sits inside
     the reference's own round-off bound); latents / waveform / PSNR of untainted items to the same tolerances as the exact path."""
@@ -103,7 +162,7 @@ def test_g4_fixture_in_bf16x6_mode(name, dev):
     net = build_proposed(gi.model_state(seed, books, K), rvq_books=books, rvq_embed=K, device=dev)
     a, t = gi.pe_inputs(B, seed)
     tr = lambda x: np.transpose(x, (1, 0, 2))
-    ops.set_arith("bf16x6")
+    ops.set_arith(mode)
     try:
         z_run, codes, idx = net.encode_latents_with_indices(a.to(dev), t.to(dev), books_use=use)
         y = net.forward_eval(a.to(dev), t.to(dev), books_use=use)
@@ -115,7 +174,7 @@ def test_g4_fixture_in_bf16x6_mode(name, dev):
     taint |= gi.check_indices(tr(idx.cpu().numpy()), tr(g[f"{name}.idx"]), tr(g[f"{name}.margin"]), tr(g[f"{name}.scale"]), "RVQ idx")
     n_dec = codes.numel() + idx.numel()
     n_eq = int((codes.cpu().numpy() == g[f"{name}.codes"]).sum() + (idx.cpu().numpy() == g[f"{name}.idx"]).sum())
-    print(f"bf16x6 vs reference fixture {name}: {n_eq}/{n_dec} indices equal, {int(taint.sum())}/{len(taint)} items with a flip inside the margin bound")
+    print(f"{mode} vs reference fixture {name}: {n_eq}/{n_dec} indices equal, {int(taint.sum())}/{len(taint)} items with a flip inside the margin bound")
     ok = ~taint
     if ok.any():
         want = g[f"{name}.z_run"]

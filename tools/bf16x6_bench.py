@@ -30,6 +30,9 @@ for name, C, T in (("enc.b2", 256, 3000), ("enc.b3", 512, 600), ("dec.b0", 768, 
         t_exact = timeit(lambda: ops.conv1d(x, wp, C, 7, bias=bias, dil=dil, pad=3 * dil, alpha_out=alpha))
         t_split = timeit(lambda: ops.bf16x3_split(x))
         t_n = timeit(lambda: ops.conv1d_k7_bf16x6(xs, wq, B, C, T, C, dil, bias=bias, alpha_out=alpha))
+        xh, xam = ops.f16x2_split(x); wh, wam = ops.pack_conv1d_k7_f16x2(w)
+        t_hs = timeit(lambda: ops.f16x2_split(x))
+        t_h = timeit(lambda: ops.conv1d_k7_f16x3(xh, xam, wh, wam, B, C, T, C, dil, bias=bias, alpha_out=alpha))
         print(f"{name}.k7d{dil}  C {C:4d} T {T:5d}  exact {t_exact:7.3f} ms {flops/t_exact*1e-9:6.1f} TF | split {t_split:6.3f} ms | "
-              f"bf16x6 {t_n:7.3f} ms {flops/t_n*1e-9:6.1f} TF | with the split {flops/(t_n+t_split)*1e-9:6.1f} TF", flush=True)
-        del x, xs
+              f"bf16x6 {t_n:7.3f} ms {flops/t_n*1e-9:6.1f} TF | with the split {flops/(t_n+t_split)*1e-9:6.1f} TF || f16x3 {t_h:7.3f} ms {flops/t_h*1e-9:6.1f} TF, split {t_hs:6.3f} ms, together {flops/(t_h+t_hs)*1e-9:6.1f} TF", flush=True)
+        del x, xs, xh
