@@ -157,7 +157,10 @@ def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x
     w7q: the three-piece bf16 image of the 7-tap weights -- given only in the opt-in "bf16x6" mode for a wide unit."""
     x = _dev(x, "x")
     B, C, T = x.shape
-    if _lib.lib().mvq_residual_unit_scratch_floats(B, C, T, dil) == 0:
+    # the fused single-launch form, unless an opt-in arithmetic mode claims the unit's 7-tap conv (then: split + matrix-core conv +
+    # the exact 1x1 with its skip, as for the wide units)
+    unfuse = w7q is not None and x_snaked is not None and os.environ.get("MVQ_ARITH_KEEP_FUSED") != "1"
+    if _lib.lib().mvq_residual_unit_scratch_floats(B, C, T, dil) == 0 and not unfuse:
         return residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next, alpha_dual, tvalid, x_snaked)
     if x_snaked is not None and w7q is not None and _ARITH == "f16x3":     # opt-in modes (set_arith): non-parity, fp32-class
         xs, xamax = f16x2_split(x_snaked)
