@@ -62,4 +62,11 @@ echo "[9] multi-rank plumbing on one device: two-rank gloo rehearsal through the
 MVQ_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --batch 32 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_2rank_one_device_rehearsal.json" 2> "$OUT/rehearsal.err" || exit 91
 MVQ_BENCH_ONE_DEVICE=1 MVQ_BENCH_REHEARSE_RCCL_FAILURE=1 timeout -k 10 120 python3 bench.py --gpus 2 --batch 8 --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/rccl_failure_rehearsal.out" 2> "$OUT/rccl_failure_rehearsal.err"
 echo "failure rehearsal exit code: $?" >> "$OUT/rccl_failure_rehearsal.err"
+echo "[10] opt-in arithmetic modes (NON-PARITY; DESIGN.md section 6d): their own bench lines next to the default one of step 6 (same box), kernel trace of f16x3"
+for M in bf16x6 f16x3; do
+    python3 bench.py --arith $M --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_arith_$M.json" 2> "$OUT/bench_arith_$M.err" || exit 101
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ks_f16x3" -- python3 bench.py --arith f16x3 $BENCH_ARGS > "$OUT/bench_arith_f16x3_under_rocprof.json" 2> "$OUT/ks_f16x3.err" || exit 102
+cp "$(ls $OUT/ks_f16x3/*/*kernel_stats.csv | tail -1)" "$OUT/kernel_stats_bench_arith_f16x3_B256.csv" || exit 103
+python3 tools/bf16x6_bench.py 256 > "$OUT/arith_layers_B256.txt" 2> "$OUT/arith_layers.err" || exit 104
 echo done
