@@ -502,28 +502,17 @@ static hipError_t launch_f16_amax(const float* x, unsigned* amax, int items, siz
     hipLaunchKernelGGL(f16_amax_kernel, dim3(bx, (unsigned)items), dim3(256), 0, s, x, amax, per_item);
     return hipGetLastError();
 }
+// (Measured and not kept, profiles/r04_timing_experiments.json::f16_split_groups: the two passes over groups of items that fit the
+// Infinity Cache, so that the split's read would hit it -- 231 -> 246 ms per step at 128 MB groups, 254 at 64 MB: the extra, smaller
+// launches cost more than the cached read saves.)
 hipError_t launch_f16x2_split(const float* x, void* xs, unsigned* xamax, int batch, int c, int t, hipStream_t s)
 {
-    const size_t per_item = (size_t)c * t;
-    if ((size_t)batch * per_item == 0) return hipSuccess;
-    // The maximum pass and the split pass both read x.  Items are independent, so the two passes run over groups of items whose
-    // fp32 image fits the 256 MB Infinity Cache with room to spare (128 MB): the split's read of a group then comes out of the cache
-    // the maximum pass just filled, not out of HBM.  MVQ_F16_SPLIT_GROUP_MB: A/B override (0 = one group).
-    static const size_t group_bytes = [] { const char* e = getenv("MVQ_F16_SPLIT_GROUP_MB"); return (size_t)(e ? atol(e) : 128) << 20; }();
-    size_t g = group_bytes ? group_bytes / (per_item * sizeof(float)) : (size_t)batch;
-    g = g < 1 ? 1 : (g > (size_t)batch ? (size_t)batch : g);
-    for (size_t b0 = 0; b0 < (size_t)batch; b0 += g) {
-        const int nb = (int)((size_t)batch - b0 < g ? (size_t)batch - b0 : g);
-        const float* xg = x + b0 * per_item;
-        hipError_t e = launch_f16_amax(xg, xamax + b0, nb, per_item, s);
-        if (e != hipSuccess) return e;
-        const size_t total = (size_t)nb * (c / 8) * t;
-        hipLaunchKernelGGL(f16x2_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xg,
-                           reinterpret_cast<f16x8*>(xs) + b0 * (size_t)(c / 8) * 2 * t, xamax + b0, c, t, total);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
+    const size_t total = (size_t)batch * (c / 8) * t;
+    if (total == 0) return hipSuccess;
+    const hipError_t e = launch_f16_amax(x, xamax, batch, (size_t)c * t, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(f16x2_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, reinterpret_cast<f16x8*>(xs), xamax, c, t, total);
+    return hipGetLastError();
 }
 hipError_t launch_f16x2_pack_k7(const float* w, void* wq, unsigned* wamax, int cout, int cin, hipStream_t s)
 {
