@@ -519,7 +519,7 @@ def main():
             # a bf16x6 kernel (opt-in mode only) spends six bf16 MFMA products per algorithmic fp32 product: its ceiling is the dense
             # bf16 MFMA peak / 6, in the same algorithmic TFLOP/s the other kernels are quoted in
             peak = FP32_MFMA_PEAK_TFLOPS
-            if "bf16x6" in name:                                   # last template argument = pieces per operand: 3 -> six products, 2 -> three
+            if name.startswith("conv_k7_pieces_kernel"):           # last template argument = pieces per operand: 3 -> six products, 2 -> three
                 peak = BF16_MFMA_PEAK_TFLOPS / (3.0 if name.rstrip(">").endswith(", 2") else 6.0)
             line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak,
                                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,

@@ -249,7 +249,7 @@ __device__ __forceinline__ void vm_wait_dyn(int n)
 
 template <int DIL, int MT, int NT, int WM, int WN, int NST, int NP>
 __global__ __attribute__((amdgpu_flat_work_group_size(1, 64 * WM * WN), amdgpu_waves_per_eu(2)))
-void conv_k7_bf16x6_kernel(const K7BfArgs a)
+void conv_k7_pieces_kernel(const K7BfArgs a)
 {
     using C = K7BfCfg<DIL, MT, NT, WM, WN, NST, NP>;
     static_assert(NP == 3 || NP == 2, "three bf16 pieces (six products) or two fp16 pieces (three products)");
@@ -427,7 +427,7 @@ static hipError_t launch_k7bf(const K7BfArgs& a_in, hipStream_t s)
     if (a_in.Cout % C::BM != 0) return hipErrorInvalidValue;
     K7BfArgs a = a_in;
     a.n_tiles = (a.T + C::BN - 1) / C::BN;
-    auto kern = conv_k7_bf16x6_kernel<DIL, MT, NT, WM, WN, NST, NP>;
+    auto kern = conv_k7_pieces_kernel<DIL, MT, NT, WM, WN, NST, NP>;
     {
         static BigLdsOptIn opt;
         const hipError_t e = opt.ensure(reinterpret_cast<const void*>(kern));
@@ -436,7 +436,7 @@ static hipError_t launch_k7bf(const K7BfArgs& a_in, hipStream_t s)
     int pi = -1;
     if (prof_enabled()) {
         char nm[96];
-        snprintf(nm, sizeof(nm), "conv_k7_bf16x6_kernel<%d, %d, %d, %d, %d, %d, %d>", DIL, MT, NT, WM, WN, NST, NP);
+        snprintf(nm, sizeof(nm), "conv_k7_pieces_kernel<%d, %d, %d, %d, %d, %d, %d>", DIL, MT, NT, WM, WN, NST, NP);
         const int cols = a.tvalid > 0 ? a.tvalid : a.T;
         pi = prof_begin(nm, 2.0 * a.Cin * 7.0 * a.Cout * (double)cols * a.B, s);
     }
@@ -455,6 +455,14 @@ hipError_t launch_bf16x3_split(const float* x, void* xs, int batch, int c, int t
 
 // rows per weight slice = the row tile of the kernel that will read the image: 128 where Cout allows, else 96 (C = 192)
 int bf16x6_tile_rows(int cout) { return cout % 128 == 0 ? 128 : (cout % 96 == 0 ? 96 : 0); }
+// f16x3 (two pieces: smaller slices): a 192-row tile on 2 x 2 waves where it divides Cout and 128 does not (C = 192: the activation
+// tile is staged once instead of twice, 10 instead of 12 operand reads per 18 MFMAs); MVQ_F16_NO192=1: A/B knob
+int f16x3_tile_rows(int cout)
+{
+    static const bool no192 = getenv("MVQ_F16_NO192") != nullptr;
+    if (cout % 128 != 0 && cout % 192 == 0 && !no192) return 192;
+    return bf16x6_tile_rows(cout);
+}
 
 hipError_t launch_bf16x3_pack_k7(const float* w, void* wq, int cout, int cin, hipStream_t s)
 {
@@ -516,7 +524,7 @@ hipError_t launch_f16x2_split(const float* x, void* xs, unsigned* xamax, int bat
 }
 hipError_t launch_f16x2_pack_k7(const float* w, void* wq, unsigned* wamax, int cout, int cin, hipStream_t s)
 {
-    const int bm = bf16x6_tile_rows(cout);
+    const int bm = f16x3_tile_rows(cout);
     if (bm == 0) return hipErrorInvalidValue;
     const hipError_t e = launch_f16_amax(w, wamax, 1, (size_t)cout * cin * 7, s);
     if (e != hipSuccess) return e;
@@ -530,8 +538,14 @@ hipError_t launch_conv_k7_f16x3(const void* xs, const unsigned* xamax, const voi
     K7BfArgs a{};
     a.xs = reinterpret_cast<const bf16x8*>(xs); a.wq = reinterpret_cast<const bf16x8*>(wq); a.bias = bias; a.alpha_out = alpha_out; a.y = y;
     a.B = batch; a.Cin = cin; a.Cout = cout; a.T = t; a.tvalid = tvalid; a.xamax = xamax; a.wamax = wamax;
-    const int bm = bf16x6_tile_rows(cout);
-    if (bm == 96) {
+    const int bm = f16x3_tile_rows(cout);
+    if (bm == 192) {
+        switch (dil) {
+            case 1: return launch_k7bf<1, 3, 2, 2, 2, 3, 2>(a, s);
+            case 3: return launch_k7bf<3, 3, 2, 2, 2, 3, 2>(a, s);
+            case 9: return launch_k7bf<9, 3, 2, 2, 2, 3, 2>(a, s);
+        }
+    } else if (bm == 96) {
         switch (dil) {
             case 1: return launch_k7bf<1, 3, 1, 1, 4, 3, 2>(a, s);
             case 3: return launch_k7bf<3, 3, 1, 1, 4, 3, 2>(a, s);
