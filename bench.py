@@ -307,8 +307,6 @@ def main():
 
     import multimodal_vqvae_compression_audio_tactile_amd as mvq
     from multimodal_vqvae_compression_audio_tactile_amd import ops, synth
-    if args.arith != "f32" and args.workload == "train":
-        raise SystemExit("bench.py: --arith other than f32 is an inference-only, opt-in mode (DESIGN.md section 6d)")
     ops.set_arith(args.arith)                                    # "f32" unless the opt-in, non-parity mode was asked for
 
     sd = synth.proposed_model_state(7, rvq_books=args.books, rvq_embed=args.embed)

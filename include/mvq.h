@@ -400,12 +400,18 @@ int mvq_conv_transpose1d_packed_rows_f32(const float* x, const float* wp, const 
  *                               cout % 128 == 0 or cout % 96 == 0, cin % 16 == 0
  *   mvq_conv1d_k7_bf16x6_f32    y[batch, cout, t] = snake_out(conv7_dil(xs) + bias), 'same' padding 3 * dil, dil in {1, 3, 9};
  *                               xs already carries the input Snake (the producer's dual output); tvalid as for the
- *                               zero-padded rows above (0 = every column is data). */
+ *                               zero-padded rows above (0 = every column is data).
+ * Training config (Decoder.forward_saving / backward_input; all optional, NULL otherwise):
+ *   y2 != NULL       dual output: y = conv + bias (the pre-activation the backward saves), y2 = snake_out(y) (what the 1x1 conv reads)
+ *   pack ... dgrad=1 the INPUT-GRADIENT image of a forward weight w[c, m, 7] (cout = the forward Cin, cin = the forward Cout):
+ *                    W'[m][c][k] = w[c][m][6 - k]; the same conv call on the output gradient then is the gradient w.r.t. the input
+ *   dsn_src, dsn_alpha, residual   the input-gradient epilogue of mvq_conv1d_dgrad_f32: v = acc * d snake(dsn_src)/dx + residual */
 size_t mvq_bf16x3_split_bytes(int batch, int c, int t);
 int mvq_bf16x3_split_f32(const float* x, void* xs, int batch, int c, int t, void* stream);
 size_t mvq_conv1d_k7_bf16x3_packed_bytes(int cout, int cin);
-int mvq_conv1d_k7_pack_bf16x3(const float* w, void* wq, int cout, int cin, void* stream);
-int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y,
+int mvq_conv1d_k7_pack_bf16x3(const float* w, void* wq, int cout, int cin, int dgrad, void* stream);
+int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y, float* y2,
+                             const float* dsn_src, const float* dsn_alpha, const float* residual,
                              int batch, int cin, int t, int cout, int dil, int tvalid, void* stream);
 
 /* The same opt-in departure with TWO fp16 pieces per operand and THREE piece products ("f16x3"): half the matrix work of bf16x6.
@@ -419,9 +425,10 @@ int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, 
  *   mvq_conv1d_k7_f16x3_f32   as mvq_conv1d_k7_bf16x6_f32 */
 int mvq_f16x2_split_f32(const float* x, void* xs, uint32_t* xamax, int batch, int c, int t, void* stream);
 size_t mvq_conv1d_k7_f16x2_packed_bytes(int cout, int cin);
-int mvq_conv1d_k7_pack_f16x2(const float* w, void* wq, uint32_t* wamax, int cout, int cin, void* stream);
+int mvq_conv1d_k7_pack_f16x2(const float* w, void* wq, uint32_t* wamax, int cout, int cin, int dgrad, void* stream);
 int mvq_conv1d_k7_f16x3_f32(const void* xs, const uint32_t* xamax, const void* wq, const uint32_t* wamax, const float* bias,
-                            const float* alpha_out, float* y, int batch, int cin, int t, int cout, int dil, int tvalid, void* stream);
+                            const float* alpha_out, float* y, float* y2, const float* dsn_src, const float* dsn_alpha,
+                            const float* residual, int batch, int cin, int t, int cout, int dil, int tvalid, void* stream);
 
 /* Polyphase sinc resampler: torchaudio.transforms.Resample(orig, new) as the reference
  * calls it on every file (Training/compare_dacvsproposal_5.py:110-113, Evaluation/dac_vcpwq_proposed6_latency.py:151-156).

@@ -42,12 +42,12 @@ EXPORTS = {
     "mvq_bf16x3_split_bytes": (c_size_t, [c_int] * 3),
     "mvq_bf16x3_split_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mvq_conv1d_k7_bf16x3_packed_bytes": (c_size_t, [c_int] * 2),
-    "mvq_conv1d_k7_pack_bf16x3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "mvq_conv1d_k7_bf16x6_f32": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "mvq_conv1d_k7_pack_bf16x3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mvq_conv1d_k7_bf16x6_f32": (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p]),
     "mvq_f16x2_split_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mvq_conv1d_k7_f16x2_packed_bytes": (c_size_t, [c_int] * 2),
-    "mvq_conv1d_k7_pack_f16x2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "mvq_conv1d_k7_f16x3_f32": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
+    "mvq_conv1d_k7_pack_f16x2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mvq_conv1d_k7_f16x3_f32": (c_int, [c_void_p] * 11 + [c_int] * 6 + [c_void_p]),
     "mvq_residual_unit_scratch_floats": (c_size_t, [c_int] * 4),
     "mvq_residual_unit_kernel_name": (c_int, [c_int, c_int, c_char_p, c_int]),
     "mvq_residual_unit_f32": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p]),

@@ -254,16 +254,17 @@ size_t mvq_conv1d_k7_bf16x3_packed_bytes(int cout, int cin)
     if (cout <= 0 || cin <= 0 || mvq::bf16x6_tile_rows(cout) == 0 || cin % 16 != 0) return 0;
     return (size_t)cout * cin * 7 * 6;
 }
-int mvq_conv1d_k7_pack_bf16x3(const float* w, void* wq, int cout, int cin, void* stream)
+int mvq_conv1d_k7_pack_bf16x3(const float* w, void* wq, int cout, int cin, int dgrad, void* stream)
 {
     if (cout <= 0 || cin <= 0 || mvq::bf16x6_tile_rows(cout) == 0 || cin % 16 != 0)
         return fail(MVQ_EINVAL, "conv1d_k7_pack_bf16x3: Cout %d must be a multiple of 128 or 96 and Cin %d of 16", cout, cin);
     if (!w || !wq) return fail(MVQ_EINVAL, "conv1d_k7_pack_bf16x3: null tensor");
     if ((reinterpret_cast<uintptr_t>(wq) & 15) != 0) return fail(MVQ_EINVAL, "conv1d_k7_pack_bf16x3: wq must be 16-byte aligned");
-    const hipError_t e = mvq::launch_bf16x3_pack_k7(w, wq, cout, cin, S(stream));
+    const hipError_t e = mvq::launch_bf16x3_pack_k7(w, wq, cout, cin, dgrad != 0, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_k7_pack_bf16x3");
 }
-int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y,
+int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y, float* y2,
+                             const float* dsn_src, const float* dsn_alpha, const float* residual,
                              int batch, int cin, int t, int cout, int dil, int tvalid, void* stream)
 {
     if (batch < 0 || cin <= 0 || cout <= 0 || t < 0 || mvq::bf16x6_tile_rows(cout) == 0 || cin % 16 != 0)
@@ -275,7 +276,10 @@ int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, 
     if (((reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(wq)) & 15) != 0)
         return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: xs / wq must be 16-byte aligned");
     if ((long long)batch * ((t + 127) / 128) > 0x7fffffffLL) return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: grid too large");
-    const hipError_t e = mvq::launch_conv_k7_bf16x6(xs, wq, bias, alpha_out, y, batch, cin, t, cout, dil, tvalid, S(stream));
+    if (y2 && !alpha_out) return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: the dual output needs alpha_out");
+    if ((dsn_src != nullptr) != (dsn_alpha != nullptr)) return fail(MVQ_EINVAL, "conv1d_k7_bf16x6: dsn_src and dsn_alpha go together");
+    mvq::K7Extra ex; ex.y2 = y2; ex.dsn_src = dsn_src; ex.dsn_alpha = dsn_alpha; ex.residual = residual;
+    const hipError_t e = mvq::launch_conv_k7_bf16x6(xs, wq, bias, alpha_out, y, batch, cin, t, cout, dil, tvalid, ex, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_k7_bf16x6");
 }
 
@@ -294,17 +298,18 @@ size_t mvq_conv1d_k7_f16x2_packed_bytes(int cout, int cin)
     if (cout <= 0 || cin <= 0 || mvq::bf16x6_tile_rows(cout) == 0 || cin % 16 != 0) return 0;
     return (size_t)cout * cin * 7 * 4;
 }
-int mvq_conv1d_k7_pack_f16x2(const float* w, void* wq, uint32_t* wamax, int cout, int cin, void* stream)
+int mvq_conv1d_k7_pack_f16x2(const float* w, void* wq, uint32_t* wamax, int cout, int cin, int dgrad, void* stream)
 {
     if (cout <= 0 || cin <= 0 || mvq::bf16x6_tile_rows(cout) == 0 || cin % 16 != 0)
         return fail(MVQ_EINVAL, "conv1d_k7_pack_f16x2: Cout %d must be a multiple of 128 or 96 and Cin %d of 16", cout, cin);
     if (!w || !wq || !wamax) return fail(MVQ_EINVAL, "conv1d_k7_pack_f16x2: null tensor");
     if ((reinterpret_cast<uintptr_t>(wq) & 15) != 0) return fail(MVQ_EINVAL, "conv1d_k7_pack_f16x2: wq must be 16-byte aligned");
-    const hipError_t e = mvq::launch_f16x2_pack_k7(w, wq, wamax, cout, cin, S(stream));
+    const hipError_t e = mvq::launch_f16x2_pack_k7(w, wq, wamax, cout, cin, dgrad != 0, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_k7_pack_f16x2");
 }
 int mvq_conv1d_k7_f16x3_f32(const void* xs, const uint32_t* xamax, const void* wq, const uint32_t* wamax, const float* bias,
-                            const float* alpha_out, float* y, int batch, int cin, int t, int cout, int dil, int tvalid, void* stream)
+                            const float* alpha_out, float* y, float* y2, const float* dsn_src, const float* dsn_alpha,
+                            const float* residual, int batch, int cin, int t, int cout, int dil, int tvalid, void* stream)
 {
     if (batch < 0 || cin <= 0 || cout <= 0 || t < 0 || mvq::bf16x6_tile_rows(cout) == 0 || cin % 16 != 0)
         return fail(MVQ_EINVAL, "conv1d_k7_f16x3: bad shape B=%d Cin=%d T=%d Cout=%d (Cout %% 128 or 96, Cin %% 16)", batch, cin, t, cout);
@@ -315,7 +320,10 @@ int mvq_conv1d_k7_f16x3_f32(const void* xs, const uint32_t* xamax, const void* w
     if (((reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(wq)) & 15) != 0)
         return fail(MVQ_EINVAL, "conv1d_k7_f16x3: xs / wq must be 16-byte aligned");
     if ((long long)batch * ((t + 127) / 128) > 0x7fffffffLL) return fail(MVQ_EINVAL, "conv1d_k7_f16x3: grid too large");
-    const hipError_t e = mvq::launch_conv_k7_f16x3(xs, xamax, wq, wamax, bias, alpha_out, y, batch, cin, t, cout, dil, tvalid, S(stream));
+    if (y2 && !alpha_out) return fail(MVQ_EINVAL, "conv1d_k7_f16x3: the dual output needs alpha_out");
+    if ((dsn_src != nullptr) != (dsn_alpha != nullptr)) return fail(MVQ_EINVAL, "conv1d_k7_f16x3: dsn_src and dsn_alpha go together");
+    mvq::K7Extra ex; ex.y2 = y2; ex.dsn_src = dsn_src; ex.dsn_alpha = dsn_alpha; ex.residual = residual;
+    const hipError_t e = mvq::launch_conv_k7_f16x3(xs, xamax, wq, wamax, bias, alpha_out, y, batch, cin, t, cout, dil, tvalid, ex, S(stream));
     return e == hipSuccess ? MVQ_OK : hipfail(e, "conv1d_k7_f16x3");
 }
 

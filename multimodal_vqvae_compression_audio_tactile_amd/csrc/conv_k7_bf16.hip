@@ -19,7 +19,7 @@
 // one row / time step: a single conflict-free ds_read_b128 (consecutive lanes 16 bytes apart).  Both operands reach LDS by
 // global -> LDS DMA only (no register staging, no VALU in the K loop): the activation tile of a channel block (all seven
 // taps read it at offsets of tap * DIL) is double-buffered, the weight slices run through a ring of three.
-#include "conv1d_mfma.hpp"
+#include "conv_dispatch.hpp"
 
 namespace mvq {
 
@@ -60,7 +60,9 @@ __global__ void bf16x3_split_kernel(const float* __restrict__ x, bf16x8* __restr
 // w[Cout][Cin][7] fp32 -> wq (layout above).  One thread per (row tile, channel block, tap, octet, row): it splits its eight weights
 // once and stores the three 16-byte fragments (one per piece).  (A first form -- one thread per fragment, picking its piece out of a
 // local array by a run-time index -- produced sporadically wrong fragments on the device; no run-time register indexing here.)
-__global__ void bf16x3_pack_k7_kernel(const float* __restrict__ w, bf16x8* __restrict__ wq, int Cout, int Cin, int BM, size_t total)
+// flip != 0: the INPUT-GRADIENT image of a forward weight w[Cin][Cout][7] (forward Cout = this Cin): row m = forward input channel,
+// k-channel = forward output channel, taps reversed -- W'[m][c][k] = w[c][m][6 - k] (stride-1 'same' conv: same dilation and padding)
+__global__ void bf16x3_pack_k7_kernel(const float* __restrict__ w, bf16x8* __restrict__ wq, int Cout, int Cin, int BM, int flip, size_t total)
 {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
@@ -78,7 +80,7 @@ __global__ void bf16x3_pack_k7_kernel(const float* __restrict__ w, bf16x8* __res
     for (int j = 0; j < 8; ++j) {
         const int ci = cb * 16 + h * 8 + j;
         __bf16 a, b, c;
-        split3(w[((size_t)co * Cin + ci) * 7 + tap], a, b, c);
+        split3(flip ? w[((size_t)ci * Cout + co) * 7 + (6 - tap)] : w[((size_t)co * Cin + ci) * 7 + tap], a, b, c);
         q0[j] = a; q1[j] = b; q2[j] = c;
     }
     // fragment (mt, cb, tap, piece, h, m)
@@ -171,7 +173,7 @@ __global__ void f16x2_split_kernel(const float* __restrict__ x, f16x8* __restric
 
 // w[Cout][Cin][7] fp32 -> wq [Cout/BM][Cin/16][7][2 pieces][2 octets][BM][8] fp16 under the tensor's scale
 __global__ void f16x2_pack_k7_kernel(const float* __restrict__ w, f16x8* __restrict__ wq, const unsigned* __restrict__ amax, int Cout, int Cin,
-                                     int BM, size_t total)
+                                     int BM, int flip, size_t total)
 {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
@@ -189,7 +191,7 @@ __global__ void f16x2_pack_k7_kernel(const float* __restrict__ w, f16x8* __restr
     for (int j = 0; j < 8; ++j) {
         const int ci = cb * 16 + h * 8 + j;
         _Float16 a, b;
-        split2h(w[((size_t)co * Cin + ci) * 7 + tap], S, a, b);
+        split2h(flip ? w[((size_t)ci * Cout + co) * 7 + (6 - tap)] : w[((size_t)co * Cin + ci) * 7 + tap], S, a, b);
         q0[j] = a; q1[j] = b;
     }
     const size_t slice = ((size_t)mt * ncb + cb) * 7 + tap;
@@ -211,6 +213,12 @@ struct K7BfArgs {
     // applied follow from them: f16_scale_exp); null in the bf16x6 form
     const unsigned* xamax;
     const unsigned* wamax;
+    // training config (Decoder.forward_saving / backward_input in a mode):
+    float* y2;              // dual output: y = the raw value (conv + bias), y2 = snake(y, alpha_out) -- the saved pre-activation and
+                            // what the 1x1 conv consumes.  null: single output (Snake applied in place when alpha_out is given)
+    const float* dsn_src;   // input-gradient epilogue: v = acc * d snake(dsn_src)/dx (+ residual); [B][Cout][T], alpha dsn_alpha[Cout]
+    const float* dsn_alpha;
+    const float* residual;  // [B][Cout][T] added last (the gradient arriving through the skip path)
 };
 
 template <int DIL, int MT, int NT, int WM, int WN, int NST, int NP>
@@ -406,16 +414,26 @@ void conv_k7_pieces_kernel(const K7BfArgs a)
             const float bv = a.bias ? a.bias[m] : 0.0f;
             const float al = a.alpha_out ? a.alpha_out[m] : 1.0f;
             const float inv = 1.0f / (al + 1e-9f);
-            float* const yrow = a.y + ((size_t)b * a.Cout + m) * T;
+            const float dal = a.dsn_src ? a.dsn_alpha[m] : 1.0f;
+            const float dinv = 1.0f / (dal + 1e-9f);
+            const size_t rowoff = ((size_t)b * a.Cout + m) * T;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = n0 + wn * (32 * NT) + j * 32 + l31;
+                if (n >= a.T) continue;
                 float v = acc[i][j][r];
                 if constexpr (NP == 2) v = v * oscale;
                 v = v + bv;
-                if (a.alpha_out) v = det_snake(v, al, inv);
-                if (a.tvalid > 0 && n >= a.tvalid) v = 0.0f;
-                if (n < a.T) yrow[n] = v;
+                if (a.dsn_src) v = v * det_dsnake(a.dsn_src[rowoff + n], dal, dinv);     // same order as the exact dgrad epilogue
+                if (a.residual) v = v + a.residual[rowoff + n];
+                const bool tail = a.tvalid > 0 && n >= a.tvalid;
+                if (a.y2) {
+                    a.y[rowoff + n] = tail ? 0.0f : v;
+                    a.y2[rowoff + n] = tail ? 0.0f : det_snake(v, al, inv);
+                } else {
+                    if (a.alpha_out) v = det_snake(v, al, inv);
+                    a.y[rowoff + n] = tail ? 0.0f : v;
+                }
             }
         }
 }
@@ -464,12 +482,12 @@ int f16x3_tile_rows(int cout)
     return bf16x6_tile_rows(cout);
 }
 
-hipError_t launch_bf16x3_pack_k7(const float* w, void* wq, int cout, int cin, hipStream_t s)
+hipError_t launch_bf16x3_pack_k7(const float* w, void* wq, int cout, int cin, int flip, hipStream_t s)
 {
     const int bm = bf16x6_tile_rows(cout);
     if (bm == 0) return hipErrorInvalidValue;
     const size_t total = (size_t)(cout / bm) * (cin / 16) * 7 * 2 * bm;
-    hipLaunchKernelGGL(bf16x3_pack_k7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<bf16x8*>(wq), cout, cin, bm, total);
+    hipLaunchKernelGGL(bf16x3_pack_k7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<bf16x8*>(wq), cout, cin, bm, flip, total);
     return hipGetLastError();
 }
 
@@ -478,9 +496,10 @@ hipError_t launch_bf16x3_pack_k7(const float* w, void* wq, int cout, int cin, hi
 // waves with a ring of four or six slices -- the same 205-220 TFLOP/s on every layer: the loop is not waiting for its DMA, the chip
 // holds its clock down under the bf16 matrix load (MI355X guide, "clock under load").
 hipError_t launch_conv_k7_bf16x6(const void* xs, const void* wq, const float* bias, const float* alpha_out, float* y, int batch, int cin,
-                                 int t, int cout, int dil, int tvalid, hipStream_t s)
+                                 int t, int cout, int dil, int tvalid, const K7Extra& ex, hipStream_t s)
 {
     K7BfArgs a{};
+    a.y2 = ex.y2; a.dsn_src = ex.dsn_src; a.dsn_alpha = ex.dsn_alpha; a.residual = ex.residual;
     a.xs = reinterpret_cast<const bf16x8*>(xs); a.wq = reinterpret_cast<const bf16x8*>(wq); a.bias = bias; a.alpha_out = alpha_out; a.y = y;
     a.B = batch; a.Cin = cin; a.Cout = cout; a.T = t; a.tvalid = tvalid;
     const int bm = bf16x6_tile_rows(cout);
@@ -522,20 +541,22 @@ hipError_t launch_f16x2_split(const float* x, void* xs, unsigned* xamax, int bat
     hipLaunchKernelGGL(f16x2_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, reinterpret_cast<f16x8*>(xs), xamax, c, t, total);
     return hipGetLastError();
 }
-hipError_t launch_f16x2_pack_k7(const float* w, void* wq, unsigned* wamax, int cout, int cin, hipStream_t s)
+hipError_t launch_f16x2_pack_k7(const float* w, void* wq, unsigned* wamax, int cout, int cin, int flip, hipStream_t s)
 {
     const int bm = f16x3_tile_rows(cout);
     if (bm == 0) return hipErrorInvalidValue;
     const hipError_t e = launch_f16_amax(w, wamax, 1, (size_t)cout * cin * 7, s);
     if (e != hipSuccess) return e;
     const size_t total = (size_t)(cout / bm) * (cin / 16) * 7 * 2 * bm;
-    hipLaunchKernelGGL(f16x2_pack_k7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<f16x8*>(wq), wamax, cout, cin, bm, total);
+    hipLaunchKernelGGL(f16x2_pack_k7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<f16x8*>(wq), wamax, cout, cin, bm, flip, total);
     return hipGetLastError();
 }
 hipError_t launch_conv_k7_f16x3(const void* xs, const unsigned* xamax, const void* wq, const unsigned* wamax, const float* bias,
-                                const float* alpha_out, float* y, int batch, int cin, int t, int cout, int dil, int tvalid, hipStream_t s)
+                                const float* alpha_out, float* y, int batch, int cin, int t, int cout, int dil, int tvalid, const K7Extra& ex,
+                                hipStream_t s)
 {
     K7BfArgs a{};
+    a.y2 = ex.y2; a.dsn_src = ex.dsn_src; a.dsn_alpha = ex.dsn_alpha; a.residual = ex.residual;
     a.xs = reinterpret_cast<const bf16x8*>(xs); a.wq = reinterpret_cast<const bf16x8*>(wq); a.bias = bias; a.alpha_out = alpha_out; a.y = y;
     a.B = batch; a.Cin = cin; a.Cout = cout; a.T = t; a.tvalid = tvalid; a.xamax = xamax; a.wamax = wamax;
     const int bm = f16x3_tile_rows(cout);

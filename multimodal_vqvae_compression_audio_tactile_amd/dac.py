@@ -113,12 +113,37 @@ class WNConv1d(_WNKeys, nn.Module):
             self._packed_dg = _Packed()
         return self._packed_dg.get((self.weight_g, self.weight_v), lambda: ops.pack_conv1d_dgrad(self.folded_weight()))
 
+    def mode_eligible(self) -> bool:
+        """An opt-in arithmetic mode is set and this is a layer it claims: a square 7-tap stride-1 conv of an eligible width."""
+        return self.ks == 7 and self.stride == 1 and self.cin == self.cout and ops.bf16x6_eligible(self.cin)
+
+    def packed_mode(self):
+        return self.packed_f16x2() if ops.get_arith() == "f16x3" else self.packed_bf16x3()
+
+    def packed_mode_dgrad(self):
+        """The input-gradient image of the current mode (training config: Decoder.backward_input)."""
+        mode = ops.get_arith()
+        if not hasattr(self, "_packed_mode_dg"):
+            self._packed_mode_dg = {}
+        c = self._packed_mode_dg.setdefault(mode, _Packed())
+        make = (lambda: ops.pack_conv1d_k7_f16x2(self.folded_weight(), dgrad=True)) if mode == "f16x3" else \
+               (lambda: ops.pack_conv1d_k7_bf16x3(self.folded_weight(), dgrad=True))
+        return c.get((self.weight_g, self.weight_v), make)
+
     def dgrad(self, gy, tin, dsnake_src=None, dsnake_alpha=None, residual=None):
         """Gradient w.r.t. this conv's input (length tin), times the derivative of the Snake in front of it."""
+        if self.mode_eligible() and tin == gy.shape[-1]:         # opt-in modes: the same matrix-core kernel on the flipped image
+            return ops.conv1d_k7_mode(gy, self.packed_mode_dgrad(), self.cin, self.dilation, dsn_src=dsnake_src,
+                                      dsn_alpha=dsnake_alpha, residual=residual)
         return ops.conv1d_dgrad(gy, self.packed_dgrad(), self.cin, tin, self.ks, 1, self.dilation, self.padding,
                                 dsnake_src=dsnake_src, dsnake_alpha=dsnake_alpha, residual=residual)
 
     def run(self, x, alpha_in=None, residual=None, alpha_out=None, tanh=False, alpha_dual=None, tvalid=0):
+        if (alpha_dual is not None and alpha_in is None and residual is None and alpha_out is None and not tanh
+                and self.mode_eligible()):
+            # opt-in modes, training config (Decoder.forward_saving): pre-snaked input, dual output (pre-activation + its Snake)
+            return ops.conv1d_k7_mode(x, self.packed_mode(), self.cout, self.dilation, bias=self.bias.detach(), alpha_out=alpha_dual,
+                                      tvalid=tvalid, dual=True)
         return ops.conv1d(x, self.packed(), self.cout, self.ks, bias=self.bias.detach(), stride=self.stride,
                           dil=self.dilation, pad=self.padding, alpha_in=alpha_in, residual=residual,
                           alpha_out=alpha_out, tanh=tanh, alpha_dual=alpha_dual, tvalid=tvalid)
@@ -198,7 +223,7 @@ class ResidualUnit(nn.Module):
         # opt-in "bf16x6" mode (ops.set_arith; NOT bit-identical to the oracle): the 7-tap conv of a wide unit on the bf16 matrix cores
         w7q = None
         if x_snaked is not None and ops.bf16x6_eligible(c7.cin):
-            w7q = c7.packed_f16x2() if ops.get_arith() == "f16x3" else c7.packed_bf16x3()
+            w7q = c7.packed_mode()
         return ops.residual_unit(x, c7.packed(), c7.bias.detach(), self.block[0].flat(), self.block[2].flat(),
                                  c1.packed(), c1.bias.detach(), c7.dilation, alpha_next=alpha_next, x_snaked=x_snaked,
                                  alpha_dual=alpha_dual, tvalid=tvalid, w7q=w7q)

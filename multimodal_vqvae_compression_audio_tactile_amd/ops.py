@@ -162,11 +162,8 @@ def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x
     unfuse = w7q is not None and x_snaked is not None and os.environ.get("MVQ_ARITH_KEEP_FUSED") != "1"
     if _lib.lib().mvq_residual_unit_scratch_floats(B, C, T, dil) == 0 and not unfuse:
         return residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next, alpha_dual, tvalid, x_snaked)
-    if x_snaked is not None and w7q is not None and _ARITH == "f16x3":     # opt-in modes (set_arith): non-parity, fp32-class
-        xs, xamax = f16x2_split(x_snaked)
-        h = conv1d_k7_f16x3(xs, xamax, w7q[0], w7q[1], B, C, T, C, dil, bias=b7, alpha_out=alpha_b, tvalid=tvalid)
-    elif x_snaked is not None and w7q is not None:
-        h = conv1d_k7_bf16x6(bf16x3_split(x_snaked), w7q, B, C, T, C, dil, bias=b7, alpha_out=alpha_b, tvalid=tvalid)
+    if x_snaked is not None and w7q is not None:      # opt-in modes (set_arith): non-parity, fp32-class
+        h = conv1d_k7_mode(x_snaked, w7q, C, dil, bias=b7, alpha_out=alpha_b, tvalid=tvalid)
     elif x_snaked is not None:
         h = conv1d(x_snaked, w7p, C, 7, bias=b7, dil=dil, pad=3 * dil, alpha_out=alpha_b, tvalid=tvalid)
     else:
@@ -209,24 +206,31 @@ def bf16x3_split(x):
     return xs
 
 
-def pack_conv1d_k7_bf16x3(w):
-    """Folded weights w[Cout, Cin, 7] fp32 -> the packed three-piece bf16 image of mvq_conv1d_k7_bf16x6_f32."""
+def pack_conv1d_k7_bf16x3(w, dgrad=False):
+    """Folded weights w[Cout, Cin, 7] fp32 -> the packed three-piece bf16 image of mvq_conv1d_k7_bf16x6_f32.
+    dgrad: the input-gradient image instead (rows = Cin, k-channels = Cout, taps reversed)."""
     w = _dev(w, "w").contiguous()
     cout, cin, ks = w.shape
+    if dgrad:
+        cout, cin = cin, cout
     n = _lib.lib().mvq_conv1d_k7_bf16x3_packed_bytes(cout, cin)
     if ks != 7 or n == 0:
         raise MvqError(f"pack_conv1d_k7_bf16x3: needs [Cout % 128 == 0 or % 96 == 0, Cin % 16 == 0, 7], got {tuple(w.shape)}")
     wq = torch.empty(n // 2, device=w.device, dtype=torch.int16)
-    check(_lib.lib().mvq_conv1d_k7_pack_bf16x3(w.data_ptr(), wq.data_ptr(), cout, cin, _stream()), "mvq_conv1d_k7_pack_bf16x3")
+    check(_lib.lib().mvq_conv1d_k7_pack_bf16x3(w.data_ptr(), wq.data_ptr(), cout, cin, 1 if dgrad else 0, _stream()), "mvq_conv1d_k7_pack_bf16x3")
     return wq
 
 
-def conv1d_k7_bf16x6(xs, wq, batch, cin, t, cout, dil, bias=None, alpha_out=None, tvalid=0):
-    """y[B, cout, t] = snake_out(conv7_dil(xs) + bias) on the bf16x6 matrix path; xs from bf16x3_split, wq from pack_conv1d_k7_bf16x3."""
+def conv1d_k7_bf16x6(xs, wq, batch, cin, t, cout, dil, bias=None, alpha_out=None, tvalid=0, dual=False, dsn_src=None, dsn_alpha=None,
+                     residual=None):
+    """y[B, cout, t] = snake_out(conv7_dil(xs) + bias) on the bf16x6 matrix path; xs from bf16x3_split, wq from pack_conv1d_k7_bf16x3.
+    dual: -> (conv + bias, snake_out of it).  dsn_src / dsn_alpha / residual: the input-gradient epilogue (wq packed with dgrad=True)."""
     y = torch.empty(batch, cout, t, device=xs.device, dtype=torch.float32)
-    check(_lib.lib().mvq_conv1d_k7_bf16x6_f32(xs.data_ptr(), wq.data_ptr(), _p(bias), _p(alpha_out), y.data_ptr(), batch, cin, t,
-                                              cout, dil, int(tvalid), _stream()), "mvq_conv1d_k7_bf16x6_f32")
-    return y
+    y2 = torch.empty_like(y) if dual else None
+    check(_lib.lib().mvq_conv1d_k7_bf16x6_f32(xs.data_ptr(), wq.data_ptr(), _p(bias), _p(alpha_out), y.data_ptr(), _p(y2), _p(dsn_src),
+                                              _p(dsn_alpha), _p(residual), batch, cin, t, cout, dil, int(tvalid), _stream()),
+          "mvq_conv1d_k7_bf16x6_f32")
+    return (y, y2) if dual else y
 
 
 def f16x2_split(x):
@@ -239,25 +243,47 @@ def f16x2_split(x):
     return xs, xamax
 
 
-def pack_conv1d_k7_f16x2(w):
-    """Folded weights w[Cout, Cin, 7] fp32 -> (packed two-piece fp16 image, the tensor's |w| maximum as an int32 bit pattern)."""
+def pack_conv1d_k7_f16x2(w, dgrad=False):
+    """Folded weights w[Cout, Cin, 7] fp32 -> (packed two-piece fp16 image, the tensor's |w| maximum as an int32 bit pattern).
+    dgrad: the input-gradient image instead (rows = Cin, k-channels = Cout, taps reversed)."""
     w = _dev(w, "w").contiguous()
     cout, cin, ks = w.shape
+    if dgrad:
+        cout, cin = cin, cout
     n = _lib.lib().mvq_conv1d_k7_f16x2_packed_bytes(cout, cin)
     if ks != 7 or n == 0:
         raise MvqError(f"pack_conv1d_k7_f16x2: needs [Cout % 128 == 0 or % 96 == 0, Cin % 16 == 0, 7], got {tuple(w.shape)}")
     wq = torch.empty(n // 2, device=w.device, dtype=torch.int16)
     wamax = torch.empty(1, device=w.device, dtype=torch.int32)
-    check(_lib.lib().mvq_conv1d_k7_pack_f16x2(w.data_ptr(), wq.data_ptr(), wamax.data_ptr(), cout, cin, _stream()), "mvq_conv1d_k7_pack_f16x2")
+    check(_lib.lib().mvq_conv1d_k7_pack_f16x2(w.data_ptr(), wq.data_ptr(), wamax.data_ptr(), cout, cin, 1 if dgrad else 0, _stream()),
+          "mvq_conv1d_k7_pack_f16x2")
     return wq, wamax
 
 
-def conv1d_k7_f16x3(xs, xamax, wq, wamax, batch, cin, t, cout, dil, bias=None, alpha_out=None, tvalid=0):
-    """y[B, cout, t] = snake_out(conv7_dil(xs) + bias) with two fp16 pieces per operand (three piece products)."""
+def conv1d_k7_f16x3(xs, xamax, wq, wamax, batch, cin, t, cout, dil, bias=None, alpha_out=None, tvalid=0, dual=False, dsn_src=None,
+                    dsn_alpha=None, residual=None):
+    """y[B, cout, t] = snake_out(conv7_dil(xs) + bias) with two fp16 pieces per operand (three piece products); dual / dsn_* /
+    residual as in conv1d_k7_bf16x6."""
     y = torch.empty(batch, cout, t, device=xs.device, dtype=torch.float32)
+    y2 = torch.empty_like(y) if dual else None
     check(_lib.lib().mvq_conv1d_k7_f16x3_f32(xs.data_ptr(), xamax.data_ptr(), wq.data_ptr(), wamax.data_ptr(), _p(bias), _p(alpha_out),
-                                             y.data_ptr(), batch, cin, t, cout, dil, int(tvalid), _stream()), "mvq_conv1d_k7_f16x3_f32")
-    return y
+                                             y.data_ptr(), _p(y2), _p(dsn_src), _p(dsn_alpha), _p(residual), batch, cin, t, cout, dil,
+                                             int(tvalid), _stream()), "mvq_conv1d_k7_f16x3_f32")
+    return (y, y2) if dual else y
+
+
+def conv1d_k7_mode(x, wq, cout, dil, bias=None, alpha_out=None, tvalid=0, dual=False, dsn_src=None, dsn_alpha=None, residual=None):
+    """The current opt-in mode's 7-tap conv on an fp32 input x[B, C, T]: split pass + matrix-core conv.  wq: what the layer's
+    packed_mode() / packed_mode_dgrad() returned for this mode."""
+    x = _dev(x, "x")
+    B, C, T = x.shape
+    kw = dict(bias=bias, alpha_out=alpha_out, tvalid=tvalid, dual=dual, dsn_src=dsn_src, dsn_alpha=dsn_alpha, residual=residual)
+    if _ARITH == "f16x3":
+        xs, xamax = f16x2_split(x)
+        return conv1d_k7_f16x3(xs, xamax, wq[0], wq[1], B, C, T, cout, dil, **kw)
+    if _ARITH == "bf16x6":
+        return conv1d_k7_bf16x6(bf16x3_split(x), wq, B, C, T, cout, dil, **kw)
+    raise MvqError("conv1d_k7_mode: no opt-in arithmetic mode is set")
 
 
 def conv_transpose1d(x, wp, cout, stride, pad, bias=None, alpha_in=None, alpha_out=None, alpha_dual=None, tout_rows=0,

@@ -183,3 +183,36 @@ def test_g4_fixture_in_bf16x6_mode(name, mode, dev):
         np.testing.assert_allclose(y.cpu().numpy()[ok], g[f"{name}.y"][ok], rtol=0, atol=2e-5)
         p = np.array(psnr_batch(t[..., :Tm].to(dev), y))
         assert np.max(np.abs(p - g[f"{name}.psnr"])[ok]) <= 1e-5
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "f16x3"])
+def test_decoder_training_path_in_a_mode(mode, dev):
+    """Training config in an opt-in mode: Decoder.forward_saving (dual-output 7-tap convs) and backward_input (the same kernel on the
+    flipped weight image with the Snake-derivative epilogue) against the exact path -- fp32-class agreement, and the mode really ran."""
+    from multimodal_vqvae_compression_audio_tactile_amd import Decoder, ops, synth
+    dec = Decoder(); dec.load_state_dict(synth.decoder_state(74), strict=True); dec = dec.to(dev)
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator().manual_seed(3)
+    z = (0.3 * torch.randn(3, 1024, 9, generator=g)).to(dev)
+    y0, sv0 = dec.forward_saving(z)
+    gy = torch.randn(y0.shape, generator=g).to(dev)
+    keys = [k for k in sv0 if k.endswith(".t7")]
+    t7_0 = {k: sv0[k].clone() for k in keys}
+    gz0 = dec.backward_input(sv0, gy)
+    ops.set_arith(mode)
+    try:
+        y1, sv1 = dec.forward_saving(z)
+        t7_1 = {k: sv1[k].clone() for k in keys}
+        gz1 = dec.backward_input(sv1, gy)
+        zr = z.clone().requires_grad_(True)                                  # the reference's call site: autograd through T_DEC
+        with torch.enable_grad():
+            (dec(zr) * gy).sum().backward()
+    finally:
+        ops.set_arith("f32")
+    assert not torch.equal(y1, y0) and not torch.equal(gz1, gz0), "the mode did not reach the training path"
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert rel(y1, y0) <= 2e-5 and rel(gz1, gz0) <= 5e-5, (rel(y1, y0), rel(gz1, gz0))
+    for k in keys:
+        assert rel(t7_1[k], t7_0[k]) <= 2e-5, k
+    assert torch.equal(zr.grad, gz1)
