@@ -170,8 +170,11 @@ def test_allpredar_training_gradients(dev):
 
 
 @torch.enable_grad()
-def test_training_step_matches_reference_fixture(dev):
-    """The reference's whole training step on the HIP path: AllPredAR.forward_step -> TrainingLoss (L1 + MRSTFT + MelCos)
+@pytest.mark.parametrize("arith", ["f32", "bf16x6", "f16x3"])
+def test_training_step_matches_reference_fixture(arith, dev):
+    """(arith != f32: the same yardstick applied to the OPT-IN, non-parity modes of DESIGN.md section 6d -- frozen encoders and the
+    decoder's forward / input-gradient 7-tap convs on the matrix cores.)
+    The reference's whole training step on the HIP path: AllPredAR.forward_step -> TrainingLoss (L1 + MRSTFT + MelCos)
     -> backward, against fixture G7 = the reference's own classes (tests/golden/make_golden.py).  Then clip + AdamW as
     the reference does (Training/compare_dacvsproposal_5.py:392-395) and the codebook EMA (...:396-397)."""
     import os, sys
@@ -183,9 +186,14 @@ def test_training_step_matches_reference_fixture(dev):
     net = build_proposed(gi.model_state(seed, books, K), rvq_books=books, rvq_embed=K, device=dev, cls=AllPredAR)
     a, t = gi.train_inputs()
     crit = TrainingLoss()
-    out = net.forward_step(a.to(dev), t.to(dev))
-    total = crit(out["y_hat"], out["tgt"])
-    total.backward()
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    ops.set_arith(arith)
+    try:
+        out = net.forward_step(a.to(dev), t.to(dev))
+        total = crit(out["y_hat"], out["tgt"])
+        total.backward()
+    finally:
+        ops.set_arith("f32")
     assert rel(out["r_tokens"], torch.from_numpy(G7["r_tokens"])) < 1e-5
     assert rel(out["y_hat"], torch.from_numpy(G7["y_hat"])) < 1e-5
     # Tolerances are set by a yardstick, not by hand: the fixture also holds the SAME step evaluated in float64 ("f64.*",

@@ -69,4 +69,11 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ks_f16x3" -- python3 bench.py --arith f16x3 $BENCH_ARGS > "$OUT/bench_arith_f16x3_under_rocprof.json" 2> "$OUT/ks_f16x3.err" || exit 102
 cp "$(ls $OUT/ks_f16x3/*/*kernel_stats.csv | tail -1)" "$OUT/kernel_stats_bench_arith_f16x3_B256.csv" || exit 103
 python3 tools/bf16x6_bench.py 256 > "$OUT/arith_layers_B256.txt" 2> "$OUT/arith_layers.err" || exit 104
+for M in bf16x6 f16x3; do
+    python3 bench.py --workload train --arith $M --steps 5 --warmup 3 --no-cpu-baseline > "$OUT/bench_train_arith_$M.json" 2> "$OUT/bench_train_arith_$M.err" || exit 105
+done
+for M in bf16x6 f16x3; do
+    python3 tools/corpus_eval.py --compare-arith $M > "$OUT/corpus_arith_comparison_$M.json" 2> "$OUT/corpus_cmp_$M.err" || exit 106
+done
+python3 tools/corpus_eval.py --arith f16x3 > "$OUT/corpus_eval_1gpu_f16x3.json" 2> "$OUT/corpus_f16x3.err" || exit 107
 echo done
