@@ -245,3 +245,23 @@ def test_arith_mode_switch_is_opt_in_and_validated():
       finally:
         ops.set_arith("f32")
     assert ops.get_arith() == "f32"
+
+
+def test_torch_ops_are_registered_with_shape_only_fakes():
+    """SURVEY.md section 8b, last row: the hot-path entry points as torch.ops.mi355x_vqvae.* -- every operator is registered and
+    its fake (shape-only) implementation answers on meta tensors with the shapes the HIP kernels produce (no GPU needed)."""
+    import multimodal_vqvae_compression_audio_tactile_amd.torch_ops as T
+    for name in T.REGISTERED:
+        assert hasattr(torch.ops.mi355x_vqvae, name), name
+    m = lambda *s, dtype=torch.float32: torch.empty(*s, device="meta", dtype=dtype)
+    o = torch.ops.mi355x_vqvae
+    assert o.conv1d_snake_f32(m(3, 64, 100), m(10), None, None, None, None, 128, 4, 2, 1, 1).shape == (3, 128, 50)
+    assert o.conv1d_snake_f32(m(2, 256, 75), m(10), m(256), None, m(2, 256, 75), m(256), 256, 7, 1, 27, 9).shape == (2, 256, 75)
+    assert o.conv_transpose1d_snake_f32(m(2, 1536, 75), m(10), m(768), m(1536), None, 768, 8, 4).shape == (2, 768, 600)
+    assert o.residual_unit_f32(m(2, 64, 240), m(1), m(64), m(64), m(64), m(1), m(64), 3, None).shape == (2, 64, 240)
+    q, idx = o.vq_rvq_search_f32(m(6, 96, 16), m(8, 512, 96), 3)
+    assert q.shape == (6, 96, 16) and idx.shape == (3, 96) and idx.dtype == torch.int64
+    zq, codes, lat = o.vq_cosine_rvq_f32(m(2, 1024, 75), m(32, 8, 1024), m(32, 8), m(32, 1024, 8), m(32, 1024, 8), m(32, 1024), 8)
+    assert zq.shape == (2, 1024, 75) and codes.shape == (2, 8, 75) and codes.dtype == torch.int64 and lat.shape == (2, 64, 75)
+    with pytest.raises(Exception):                       # the real implementations have no CPU path
+        o.conv1d_snake_f32(torch.zeros(1, 16, 8), torch.zeros(4), None, None, None, None, 16, 1, 1, 0, 1)

@@ -523,3 +523,25 @@ def test_dac_rvq_prepared_codebook_is_bit_identical(dev):
         b = ops.dac_rvq(z, in_w, in_b, cb, out_w, out_b, nq, nq_item=nq_item, prepared=prep)
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+def test_torch_ops_call_the_same_kernels(dev):
+    """torch.ops.mi355x_vqvae.* (last row) are the C-ABI entry points: bit-equal to the ops.* calls."""
+    import math
+    import multimodal_vqvae_compression_audio_tactile_amd.torch_ops  # noqa: F401  (registers)
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    torch.manual_seed(11)
+    o = torch.ops.mi355x_vqvae
+    x = torch.randn(2, 64, 200, device=dev); w = torch.randn(128, 64, 4, device=dev) / math.sqrt(256)
+    wp = ops.pack_conv1d(w); b = torch.randn(128, device=dev); al = torch.rand(64, device=dev) + 0.5
+    assert torch.equal(o.conv1d_snake_f32(x, wp, b, al, None, None, 128, 4, 2, 1, 1),
+                       ops.conv1d(x, wp, 128, 4, bias=b, stride=2, pad=1, alpha_in=al))
+    wt = torch.randn(64, 32, 8, device=dev) / math.sqrt(128); wtp = ops.pack_conv_transpose1d(wt, 4)
+    assert torch.equal(o.conv_transpose1d_snake_f32(x, wtp, None, al, None, 32, 4, 2), ops.conv_transpose1d(x, wtp, 32, 4, 2, alpha_in=al))
+    z = torch.randn(5, 96, 16, device=dev); books = torch.randn(4, 128, 96, device=dev) / math.sqrt(96)
+    q, idx = o.vq_rvq_search_f32(z, books, 3)
+    q2, idx2 = ops.rvq_ema_forward(z, books, n_books_use=3, return_indices=True)
+    assert torch.equal(q, q2) and torch.equal(idx, idx2)
+    bk1, bk2 = books.clone(), books.clone()
+    o.ema_update_f32(bk1, z, 0.99); ops.rvq_ema_step_(z, bk2, 0.99)
+    assert torch.equal(bk1, bk2) and not torch.equal(bk1, books)
