@@ -265,3 +265,27 @@ def test_torch_ops_are_registered_with_shape_only_fakes():
     assert zq.shape == (2, 1024, 75) and codes.shape == (2, 8, 75) and codes.dtype == torch.int64 and lat.shape == (2, 64, 75)
     with pytest.raises(Exception):                       # the real implementations have no CPU path
         o.conv1d_snake_f32(torch.zeros(1, 16, 8), torch.zeros(4), None, None, None, None, 16, 1, 1, 0, 1)
+
+
+def test_opt_in_mode_entry_points_validate_their_arguments():
+    """The bf16x6 / f16x3 entry points (include/mvq.h) refuse bad shapes before any device access, accept empty batches, and size
+    their images as documented."""
+    from multimodal_vqvae_compression_audio_tactile_amd import _lib
+    lib = _lib.lib()
+    assert lib.mvq_bf16x3_split_bytes(3, 256, 100) == 3 * 256 * 100 * 6
+    assert lib.mvq_conv1d_k7_bf16x3_packed_bytes(256, 256) == 256 * 256 * 7 * 6 and lib.mvq_conv1d_k7_f16x2_packed_bytes(192, 192) == 192 * 192 * 7 * 4
+    assert lib.mvq_conv1d_k7_bf16x3_packed_bytes(160, 160) == 0 and lib.mvq_conv1d_k7_f16x2_packed_bytes(256, 250) == 0
+    assert lib.mvq_bf16x3_split_f32(None, None, 2, 12, 16, None) == -1 and b"C % 8" in lib.mvq_last_error()
+    assert lib.mvq_bf16x3_split_f32(None, None, 0, 16, 16, None) == 0                                     # empty batch
+    assert lib.mvq_f16x2_split_f32(None, None, None, 2, 16, 16, None) == -1 and b"null" in lib.mvq_last_error()
+    assert lib.mvq_conv1d_k7_pack_bf16x3(None, None, 160, 160, 0, None) == -1 and b"128 or 96" in lib.mvq_last_error()
+    bf = lambda *a: lib.mvq_conv1d_k7_bf16x6_f32(None, None, None, None, None, None, None, None, None, *a, None)
+    #            batch cin t cout dil tvalid
+    assert bf(2, 256, 100, 256, 2, 0) == -1 and b"dilation" in lib.mvq_last_error()
+    assert bf(2, 256, 100, 160, 1, 0) == -1 and bf(2, 250, 100, 256, 1, 0) == -1
+    assert bf(2, 256, 100, 256, 3, 101) == -1 and b"tvalid" in lib.mvq_last_error()
+    assert bf(2, 256, 100, 256, 3, 0) == -1 and b"null tensor" in lib.mvq_last_error()                    # shape fine
+    assert bf(0, 256, 100, 256, 3, 0) == 0 and bf(2, 256, 0, 256, 3, 0) == 0                              # empty batch / empty rows
+    f16 = lambda *a: lib.mvq_conv1d_k7_f16x3_f32(None, None, None, None, None, None, None, None, None, None, None, *a, None)
+    assert f16(2, 192, 100, 192, 9, 0) == -1 and b"null tensor" in lib.mvq_last_error()
+    assert f16(2, 192, 100, 192, 4, 0) == -1 and f16(0, 192, 100, 192, 9, 0) == 0
