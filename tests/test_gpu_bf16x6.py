@@ -216,3 +216,53 @@ def test_decoder_training_path_in_a_mode(mode, dev):
     for k in keys:
         assert rel(t7_1[k], t7_0[k]) <= 2e-5, k
     assert torch.equal(zr.grad, gz1)
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "f16x3"])
+def test_edge_shapes_and_every_entry_point_in_a_mode(mode, dev):
+    """The shapes the exact path is tested on, in an opt-in mode: empty batch, a length that is not a multiple of the hop, a clip
+    shorter than a token, a 4-s clip, a non-finite sample, the tactile-only chain, the DAC baseline round trip at several n_q and a
+    hipGraph replay -- finite where the input is, the exact path's shapes, and fp32-class agreement with the exact path."""
+    import multimodal_vqvae_compression_audio_tactile_amd as mvq
+    from multimodal_vqvae_compression_audio_tactile_amd import ops, synth
+    from multimodal_vqvae_compression_audio_tactile_amd.graphs import GraphedCall
+    net = mvq.build_proposed(synth.proposed_model_state(7, rvq_books=8, rvq_embed=512), rvq_books=8, rvq_embed=512, device=dev)
+    mdl = mvq.DAC(); mdl.load_state_dict(synth.dac_state(7), strict=True); mdl = mdl.to(dev).eval()
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    cases = {}
+    T = 320 * 20 + 137
+    cases["ragged"] = (synth.audio_segments(2, seed=8, T=T).to(dev), synth.tactile_segments(2, seed=8, T=T).to(dev))
+    cases["4s"] = (synth.audio_segments(1, seed=9, T=96000).to(dev), synth.tactile_segments(1, seed=9, T=96000).to(dev))
+    cases["batch3"] = (synth.audio_segments(3, seed=10).to(dev), synth.tactile_segments(3, seed=10).to(dev))
+    x = synth.tactile_segments(2, seed=12).to(dev)
+
+    def run_all():
+        out = {k: net.forward_eval(a, t) for k, (a, t) in cases.items()}
+        out["tactile_only"] = net.forward_eval_tactile_only(cases["batch3"][1])
+        out["empty"] = net.forward_eval(torch.zeros(0, 1, 24000, device=dev), torch.zeros(0, 1, 24000, device=dev))
+        out["short"] = net.T_ENC(torch.zeros(2, 1, 100, device=dev))
+        for n_q in (1, 8, 32):
+            z, codes, *_ = mdl.encode(x, n_quantizers=n_q)
+            out[f"dac{n_q}"] = mdl.decode(z); out[f"codes{n_q}"] = codes
+        bad = cases["batch3"][1].clone(); bad[0, 0, 1000] = float("nan")
+        out["nan_shape"] = torch.tensor(net.forward_eval(cases["batch3"][0], bad).shape)
+        return out
+    want = run_all()
+    ops.set_arith(mode)
+    try:
+        got = run_all()
+        a1, t1 = cases["batch3"][0][:1].contiguous(), cases["batch3"][1][:1].contiguous()
+        eager = net.encode_latents(a1, t1)
+        g = GraphedCall(lambda aa, tt: net.encode_latents(aa, tt), a1, t1)
+        assert torch.equal(g(a1, t1), eager), "hipGraph replay of the mode differs from its eager run"
+        assert torch.equal(net.forward_eval(*cases["batch3"])[:1], net.forward_eval(a1, t1)), "batch row != its B = 1 run"
+    finally:
+        ops.set_arith("f32")
+    for k, w in want.items():
+        g_ = got[k]
+        assert g_.shape == w.shape, k
+        if k.startswith("codes"):
+            assert (g_ == w).double().mean() > 0.999, k
+        elif w.numel() and k != "nan_shape":
+            assert torch.isfinite(g_).all() and rel(g_, w) < 1e-3, (k, rel(g_, w))
+    assert not torch.equal(got["batch3"], want["batch3"])
