@@ -573,6 +573,17 @@ hipError_t launch_conv_k7_f16x3(const void* xs, const unsigned* xamax, const voi
             case 9: return launch_k7bf<9, 3, 1, 1, 4, 3, 2>(a, s);
         }
     } else if (bm == 128) {
+        // Rows of >= 2 048 columns: 128 x 256 tile, wave tile 64 x 128 -- 0.5 instead of 0.67 operand reads per MFMA and half the weight
+        // staging per MFMA.  The loop is power-bound, so less energy per MFMA is a higher clock (the guide's rule 28): 355 -> 365 and
+        // 368 -> 383 TFLOP/s on the T = 3 000 layers, 233.1 -> 231.0 ms per step.  MVQ_F16_NO_WIDE=1: A/B knob.
+        static const bool no_wide = getenv("MVQ_F16_NO_WIDE") != nullptr;
+        if (!no_wide && t >= 2048) {
+            switch (dil) {
+                case 1: return launch_k7bf<1, 2, 4, 2, 2, 3, 2>(a, s);
+                case 3: return launch_k7bf<3, 2, 4, 2, 2, 3, 2>(a, s);
+                case 9: return launch_k7bf<9, 2, 4, 2, 2, 3, 2>(a, s);
+            }
+        }
         switch (dil) {
             case 1: return launch_k7bf<1, 2, 2, 2, 2, 3, 2>(a, s);
             case 3: return launch_k7bf<3, 2, 2, 2, 2, 3, 2>(a, s);
