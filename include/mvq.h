@@ -419,7 +419,8 @@ int mvq_conv1d_k7_bf16x6_f32(const void* xs, const void* wq, const float* bias, 
  * the power of two that puts their largest magnitude into [2^13, 2^14) (exact); the scales are kept as the float bit patterns of
  * those maxima (xamax[batch], wamax[1], written by the split / pack calls) and undone in the conv's epilogue.  Error per product
  * <= ~3 x 2^-22 (dropped h1 g1 term + the two representation errors): about twice the rounding error of the exact fp32 chain, i.e.
- * fp32-class but looser than bf16x6; non-finite inputs are outside its contract.
+ * fp32-class; the maxima are taken over the FINITE elements, so a NaN / Inf sample contaminates its own receptive field only (as in
+ * the exact path) and does not disturb the item's scale; finite magnitudes above the fp32 range of a S are outside its contract.
  *   mvq_f16x2_split_f32       x[batch, c, t] -> xs (4 bytes per element: [batch][c/8][2 pieces][t][8] fp16), xamax[batch]
  *   mvq_conv1d_k7_pack_f16x2  w[cout, cin, 7] -> wq (mvq_conv1d_k7_f16x2_packed_bytes), wamax[1]
  *   mvq_conv1d_k7_f16x3_f32   as mvq_conv1d_k7_bf16x6_f32 */

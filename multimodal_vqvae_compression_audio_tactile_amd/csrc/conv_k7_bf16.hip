@@ -109,8 +109,9 @@ __device__ __forceinline__ float f16_pow2(int k)
 __device__ __forceinline__ float f16_scale(unsigned amax_bits) { return f16_pow2(f16_scale_exp(amax_bits)); }
 __device__ __forceinline__ float f16_inv_scale(unsigned amax_bits) { return f16_pow2(-f16_scale_exp(amax_bits)); }
 
-// amax[item] = max |x| over the item's `per_item` elements, as float bits (non-negative floats order like unsigned integers);
-// the caller zeroes amax first.  grid (blocks per item, items).
+// amax[item] = max |x| over the FINITE elements of the item's `per_item` elements, as float bits (non-negative floats order like
+// unsigned integers); the caller zeroes amax first.  grid (blocks per item, items).  A NaN / Inf sample therefore neither decides nor
+// disables the item's scale: it becomes a non-finite piece and contaminates its own receptive field only, as in the exact path.
 __global__ void f16_amax_kernel(const float* __restrict__ x, unsigned* __restrict__ amax, size_t per_item)
 {
     const float* src = x + (size_t)blockIdx.y * per_item;
@@ -123,19 +124,20 @@ __global__ void f16_amax_kernel(const float* __restrict__ x, unsigned* __restric
         for (; i + 3 * stride < n4; i += 4 * stride) {
             const uint4 a = s4[i], b = s4[i + stride], c = s4[i + 2 * stride], d = s4[i + 3 * stride];
             unsigned q;
-            q = a.x & 0x7fffffffu; m = q > m ? q : m; q = a.y & 0x7fffffffu; m = q > m ? q : m; q = a.z & 0x7fffffffu; m = q > m ? q : m; q = a.w & 0x7fffffffu; m = q > m ? q : m;
-            q = b.x & 0x7fffffffu; m = q > m ? q : m; q = b.y & 0x7fffffffu; m = q > m ? q : m; q = b.z & 0x7fffffffu; m = q > m ? q : m; q = b.w & 0x7fffffffu; m = q > m ? q : m;
-            q = c.x & 0x7fffffffu; m = q > m ? q : m; q = c.y & 0x7fffffffu; m = q > m ? q : m; q = c.z & 0x7fffffffu; m = q > m ? q : m; q = c.w & 0x7fffffffu; m = q > m ? q : m;
-            q = d.x & 0x7fffffffu; m = q > m ? q : m; q = d.y & 0x7fffffffu; m = q > m ? q : m; q = d.z & 0x7fffffffu; m = q > m ? q : m; q = d.w & 0x7fffffffu; m = q > m ? q : m;
+            q = a.x & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = a.y & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = a.z & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = a.w & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m;
+            q = b.x & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = b.y & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = b.z & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = b.w & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m;
+            q = c.x & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = c.y & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = c.z & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = c.w & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m;
+            q = d.x & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = d.y & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = d.z & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = d.w & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m;
         }
         for (; i < n4; i += stride) {
             const uint4 a = s4[i];
             unsigned q;
-            q = a.x & 0x7fffffffu; m = q > m ? q : m; q = a.y & 0x7fffffffu; m = q > m ? q : m; q = a.z & 0x7fffffffu; m = q > m ? q : m; q = a.w & 0x7fffffffu; m = q > m ? q : m;
+            q = a.x & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = a.y & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = a.z & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m; q = a.w & 0x7fffffffu; q = q < 0x7f800000u ? q : 0u; m = q > m ? q : m;
         }
     } else {
         for (size_t i = i0; i < per_item; i += stride) {
-            const unsigned u = __float_as_uint(src[i]) & 0x7fffffffu;
+            unsigned u = __float_as_uint(src[i]) & 0x7fffffffu;
+            u = u < 0x7f800000u ? u : 0u;
             m = u > m ? u : m;
         }
     }

@@ -90,9 +90,10 @@ def test_f16_split_is_bit_exact(dev):
     B, C, T = 4, 24, 91
     x = torch.randn(B, C, T, device=dev) * torch.tensor([1e-3, 1.0, 37.0, 0.0], device=dev)[:, None, None]
     x[1, 3, 7] = 250.0
+    x[2, 5, 11] = float("nan"); x[2, 6, 12] = float("inf")                  # non-finite samples do not decide the item's scale
     xs, xamax = ops.f16x2_split(x)
     xs = xs.view(torch.float16).reshape(B, C // 8, 2, T, 8)
-    am = x.abs().flatten(1).amax(1)
+    am = torch.where(torch.isfinite(x), x.abs(), torch.zeros_like(x)).flatten(1).amax(1)
     assert torch.equal(xamax.view(torch.float32), am)
     for b in range(B):
         S = _f16_scale(float(am[b]))
@@ -100,9 +101,12 @@ def test_f16_split_is_bit_exact(dev):
         h0 = a.half(); h1 = (a - h0.float()).half()
         for p, h in enumerate((h0, h1)):
             want = h.reshape(C // 8, 8, T).permute(0, 2, 1).contiguous()
-            assert (xs[b, :, p].float() == want.float()).all(), (b, p)        # value equality: a residual of an exact zero may carry either sign
+            fin = torch.isfinite(want.float()) & torch.isfinite(xs[b, :, p].float())
+            assert ((xs[b, :, p].float() == want.float()) | ~fin).all(), (b, p)   # value equality: a residual of an exact zero may carry either sign
+            assert (torch.isfinite(xs[b, :, p].float()) == torch.isfinite(want.float())).all() or p == 1
         back = (h0.float() + h1.float()) / S
-        assert ((back - x[b]).abs() <= torch.maximum(x[b].abs() * 2.0 ** -21, am[b] * 2.0 ** -37)).all()
+        ok = torch.isfinite(x[b])
+        assert ((back - x[b]).abs()[ok] <= torch.maximum(x[b].abs() * 2.0 ** -21, am[b] * 2.0 ** -37)[ok]).all()
 
 
 @pytest.mark.parametrize("C,T,dil,tvalid", [(128, 300, 1, 0), (256, 601, 3, 0), (384, 260, 9, 259), (192, 516, 9, 515)])
@@ -266,3 +270,24 @@ def test_edge_shapes_and_every_entry_point_in_a_mode(mode, dev):
         elif w.numel() and k != "nan_shape":
             assert torch.isfinite(g_).all() and rel(g_, w) < 1e-3, (k, rel(g_, w))
     assert not torch.equal(got["batch3"], want["batch3"])
+
+
+def test_f16x3_non_finite_sample_stays_local(dev):
+    """A NaN in the input of the f16x3 conv contaminates its receptive field only (the item's scale comes from the finite samples)."""
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    torch.manual_seed(2)
+    B, C, T, dil = 2, 128, 400, 3
+    x = torch.randn(B, C, T, device=dev); w = torch.randn(C, C, 7, device=dev) / math.sqrt(7 * C)
+    wq, wamax = ops.pack_conv1d_k7_f16x2(w)
+    xs0, am0 = ops.f16x2_split(x)
+    y0 = ops.conv1d_k7_f16x3(xs0, am0, wq, wamax, B, C, T, C, dil)
+    x[1, 17, 200] = float("nan")
+    xs1, am1 = ops.f16x2_split(x)
+    y1 = ops.conv1d_k7_f16x3(xs1, am1, wq, wamax, B, C, T, C, dil)
+    assert torch.equal(am1.view(torch.float32)[0], am0.view(torch.float32)[0]) and torch.isfinite(am1.view(torch.float32)).all()
+    assert torch.equal(y1[0], y0[0])                                           # the other item is untouched
+    lo, hi = 200 - 3 * dil, 200 + 3 * dil + 1
+    bad = ~torch.isfinite(y1[1])
+    assert bad[:, lo:hi].any() and not bad[:, :lo].any() and not bad[:, hi:].any()
+    keep = torch.ones(T, dtype=torch.bool, device=dev); keep[lo:hi] = False
+    assert float((y1[1][:, keep] - y0[1][:, keep]).abs().max()) <= 1e-5 * float(y0[1].abs().max())
