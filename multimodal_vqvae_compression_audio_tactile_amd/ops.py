@@ -154,7 +154,8 @@ def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x
     two conv launches (Snake on load / on store in the first, skip + next Snake in the second's epilogue).
     x_snaked: snake_a(x) already produced by the previous layer's dual output (skips the staging-time Snake);
     alpha_dual: also return snake(y_raw, alpha_dual) for the next unit -> (y, y2).
-    w7q: the three-piece bf16 image of the 7-tap weights -- given only in the opt-in "bf16x6" mode for a wide unit."""
+    w7q: the layer's packed_mode() image of the 7-tap weights -- given only in an opt-in arithmetic mode (set_arith) for a unit the
+    mode claims; None (the default) keeps every launch the exact kernel."""
     x = _dev(x, "x")
     B, C, T = x.shape
     # the fused single-launch form, unless an opt-in arithmetic mode claims the unit's 7-tap conv (then: split + matrix-core conv +
