@@ -1524,6 +1524,11 @@ inline int conv_mpad(int mrows) { const int bm = conv_tile_bm(mrows); return (mr
 inline int conv_tail_width(const ConvArgs& a)
 {
     if (a.n_base != 0 || a.n_tiles_max != 0) return 0;          // already one half of a split
+    // The tail is its own launch behind the main one: it pays off only when it can put a block on (most of) the 256 CUs.  At the
+    // reference's batch of 6 a tail launch is 18-36 blocks that each walk the whole K chain alone -- 9 such launches were 2.5 of
+    // the 14.5 ms of a 6-segment step (profiles/r05_kernel_stats_B6_inference_before.csv: 4.4 TFLOP/s) -- while the unsplit grid
+    // still fits the chip's resident slots, where a mostly empty last tile costs nothing extra.
+    if ((long)a.B * ((a.Mrows + 127) / 128) < 128) return 0;
     const int full = a.Ncols / 128, rem = a.Ncols % 128;
     if (full == 0 || rem == 0 || rem > 96) return 0;
     const int w = rem <= 64 ? 64 : 96;
