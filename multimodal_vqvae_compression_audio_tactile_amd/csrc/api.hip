@@ -164,6 +164,7 @@ unsigned mvq_build_flags(void)
     if (getenv("MVQ_ROWFAST_MAX_KB")) mvq::note_env_override(MVQ_BF_ENV_ROWFAST);
     if (getenv("MVQ_NO_TOKEN_RVQ")) mvq::note_env_override(MVQ_BF_ENV_NO_TOKEN_RVQ);
     if (getenv("MVQ_LN_TILE32")) mvq::note_env_override(0x800);
+    if (getenv("MVQ_LAT_MAX_TILES")) mvq::note_env_override(MVQ_BF_ENV_LAT_TILES);
     return mvq::conv_compile_flags() | __atomic_load_n(&mvq::g_env_flags, __ATOMIC_RELAXED);
 }
 const char* mvq_last_error(void) { return g_err; }
@@ -219,6 +220,12 @@ static hipError_t dispatch_conv1d(const mvq::ConvArgs& a, int ks, int stride, in
 {
     const int bm = mvq::conv_tile_bm(a.Cout);
     hipError_t e = hipErrorInvalidValue;
+    /* latency regime (one segment, a batch of six: conv_lat.hip): the 128-row tiling would put a block on fewer than 160 of the
+     * 256 CUs and the launch has few enough 16 x 16 tiles -> one wave per tile on v_mfma_f32_16x16x4_f32, same fma chains */
+    if (a.Cout >= 16 && a.Cin >= 32 && mvq::conv_underfilled(a) && mvq::conv_lat_wanted(a)) {
+        e = mvq::launch_conv_lat(a, ks, stride, dil, s);
+        if (e != hipErrorInvalidValue) return e;
+    }
     if (a.Cout >= 32 && a.Cin >= 32) {                 // a dense (channels x kernel) tile exists
         if (ks == 7 && stride == 1 && a.Cin % 8 == 0) e = mvq::launch_conv_k7(a, dil, bm, s);
         else if (ks == 1 && stride == 1 && dil == 1 && a.Cin % 32 == 0) e = mvq::launch_conv_k1k3(a, 1, bm, s);
@@ -231,6 +238,10 @@ static hipError_t dispatch_conv1d(const mvq::ConvArgs& a, int ks, int stride, in
 static hipError_t dispatch_convtr(const mvq::ConvArgs& a, hipStream_t s)
 {
     if (a.Cin % 32 != 0 || a.Mrows < 64) return hipErrorInvalidValue;
+    if (mvq::conv_underfilled(a) && mvq::conv_lat_wanted(a)) {
+        const hipError_t e = mvq::launch_conv_lat(a, 2, 1, 1, s);
+        if (e != hipErrorInvalidValue) return e;
+    }
     return mvq::launch_conv_tr(a, mvq::conv_tile_bm(a.Mrows), s);
 }
 

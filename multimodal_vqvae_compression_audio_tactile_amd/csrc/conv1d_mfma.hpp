@@ -127,6 +127,7 @@ struct ConvArgs {
 #define MVQ_BF_ENV_NO_DMA 0x100
 #define MVQ_BF_ENV_ROWFAST 0x200
 #define MVQ_BF_ENV_NO_TOKEN_RVQ 0x400
+#define MVQ_BF_ENV_LAT_TILES 0x1000
 constexpr unsigned conv_compile_flags()
 {
     unsigned f = 0;
@@ -1537,6 +1538,10 @@ inline int conv_tail_width(const ConvArgs& a)
 
 // Latency regime: when the 128-row tiling would leave most of the 256 CUs idle (small batch x short sequences), the
 // same kernel runs with 64 x 64 tiles -- 4x the blocks, each walking the same K chain, so results are unchanged.
+inline bool conv_underfilled(const ConvArgs& a)
+{
+    return (long)a.B * ((a.Ncols + 127) / 128) * ((a.Mrows + 127) / 128) < 160;
+}
 inline bool conv_prefer_small_tiles(const ConvArgs& a)
 {
     if (a.Mpad % 64 != 0) return false;

@@ -9,6 +9,9 @@ hipError_t launch_conv_k1k3(const ConvArgs& a, int ks, int bm, hipStream_t s);  
 hipError_t launch_conv_strided(const ConvArgs& a, int stride, int bm, hipStream_t s); // ks = 2*stride, stride 2/4/5/8
 hipError_t launch_conv_tr(const ConvArgs& a, int bm, hipStream_t s);               // polyphase ConvTranspose1d
 hipError_t launch_residual_unit_fused(const ConvArgs& a, int dil, hipStream_t s);   // C in {64, 96, 128}, dil 1/3/9
+// latency form (conv_lat.hip): 16x16x4 MFMA, one wave per 16 x 16 tile; conv_lat_wanted = the launch is small enough for it
+bool conv_lat_wanted(const ConvArgs& a);
+hipError_t launch_conv_lat(const ConvArgs& a, int ks, int stride, int dil, hipStream_t s);          // transposed: a.up_s > 1, ks = 2
 // opt-in bf16x6 / f16x3 arithmetic modes (conv_k7_bf16.hip)
 struct K7Extra {              // training-config epilogues (all optional): dual output, input-gradient Snake derivative, skip gradient
     float* y2 = nullptr; const float* dsn_src = nullptr; const float* dsn_alpha = nullptr; const float* residual = nullptr;

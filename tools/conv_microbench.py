@@ -102,6 +102,12 @@ for (name, kind, cin, cout, ks, st, dil, tin, ai, res, ao, count) in layers:
         for _ in range(n): f()
         e1.record(); torch.cuda.synchronize()
         ms = min(ms, e0.elapsed_time(e1) / n)
+    if os.environ.get("MVQ_MB_EVENTS") == "1":        # device time of the kernel(s) alone (per-launch HIP events inside the library):
+        ops.profile_begin()                            # what a latency-regime launch costs without the Python / ctypes call around it
+        for _ in range(n): f()
+        d = ops.profile_end()
+        ms = 1e3 * sum(v["seconds"] for v in d.values()) / n
+        kname = " " * 18 + "+".join(k.replace("conv1d_mfma_kernel", "mfma").replace("conv1d_lat_kernel", "LAT").replace("residual_unit_kernel", "ru") for k in d)
     tot += ms * count
     print(f"{name:18s} {kname[18:60]:42s} Cin {cin:5d} Cout {cout:5d} T {Tx:7d} {ms:8.3f} ms x{count:2d} = {ms*count:7.2f} ms  {flops/ms*1e-9:6.1f} TF")
 print(f"sum over path: {tot:.1f} ms per step")
