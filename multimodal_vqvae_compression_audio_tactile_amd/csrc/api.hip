@@ -222,7 +222,7 @@ static hipError_t dispatch_conv1d(const mvq::ConvArgs& a, int ks, int stride, in
     hipError_t e = hipErrorInvalidValue;
     /* latency regime (one segment, a batch of six: conv_lat.hip): the 128-row tiling would put a block on fewer than 160 of the
      * 256 CUs and the launch has few enough 16 x 16 tiles -> one wave per tile on v_mfma_f32_16x16x4_f32, same fma chains */
-    if (a.Cout >= 16 && a.Cin >= 32 && mvq::conv_underfilled(a) && mvq::conv_lat_wanted(a)) {
+    if (a.Cout >= 16 && a.Cin >= 32 && mvq::conv_underfilled(a) && mvq::conv_lat_wanted(a, ks)) {
         e = mvq::launch_conv_lat(a, ks, stride, dil, s);
         if (e != hipErrorInvalidValue) return e;
     }
@@ -238,10 +238,6 @@ static hipError_t dispatch_conv1d(const mvq::ConvArgs& a, int ks, int stride, in
 static hipError_t dispatch_convtr(const mvq::ConvArgs& a, hipStream_t s)
 {
     if (a.Cin % 32 != 0 || a.Mrows < 64) return hipErrorInvalidValue;
-    if (mvq::conv_underfilled(a) && mvq::conv_lat_wanted(a)) {
-        const hipError_t e = mvq::launch_conv_lat(a, 2, 1, 1, s);
-        if (e != hipErrorInvalidValue) return e;
-    }
     return mvq::launch_conv_tr(a, mvq::conv_tile_bm(a.Mrows), s);
 }
 

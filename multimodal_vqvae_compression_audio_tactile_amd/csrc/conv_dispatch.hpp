@@ -10,7 +10,7 @@ hipError_t launch_conv_strided(const ConvArgs& a, int stride, int bm, hipStream_
 hipError_t launch_conv_tr(const ConvArgs& a, int bm, hipStream_t s);               // polyphase ConvTranspose1d
 hipError_t launch_residual_unit_fused(const ConvArgs& a, int dil, hipStream_t s);   // C in {64, 96, 128}, dil 1/3/9
 // latency form (conv_lat.hip): 16x16x4 MFMA, one wave per 16 x 16 tile; conv_lat_wanted = the launch is small enough for it
-bool conv_lat_wanted(const ConvArgs& a);
+bool conv_lat_wanted(const ConvArgs& a, int ks);
 hipError_t launch_conv_lat(const ConvArgs& a, int ks, int stride, int dil, hipStream_t s);          // transposed: a.up_s > 1, ks = 2
 // opt-in bf16x6 / f16x3 arithmetic modes (conv_k7_bf16.hip)
 struct K7Extra {              // training-config epilogues (all optional): dual output, input-gradient Snake derivative, skip gradient
