@@ -410,27 +410,60 @@ __global__ __launch_bounds__(256) void layernorm_c_tile_kernel(
     }
     __syncthreads();
     if (tid < LN_TOK) {
+        // The two ordered chains (sum, then squared deviations: 2 C dependent operations) are what a small call waits for.  Their
+        // LDS operands are fetched one batch AHEAD of the chain (round 5: each batch of 16 reads used to be issued only after the
+        // previous batch's additions -- 128 exposed LDS latencies per token at C = 1024, about half of the call).
+        const float* col = tile + tid;
         float s = 0.0f;
         int c = 0;
-        for (; c + 16 <= C; c += 16) {                            // operands first, then the (ordered) chain
-            float v[16];
+        float v[16], w[16];
+        if (C >= 16) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = tile[(c + u) * LN_TOK + tid];
+            for (int u = 0; u < 16; ++u) v[u] = col[u * LN_TOK];
+        }
+        for (; c + 32 <= C; c += 32) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = col[(c + 16 + u) * LN_TOK];
 #pragma unroll
             for (int u = 0; u < 16; ++u) s = s + v[u];
+            if (c + 48 <= C) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = col[(c + 32 + u) * LN_TOK];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s = s + w[u];
         }
-        for (; c < C; ++c) s = s + tile[c * LN_TOK + tid];
+        if (c + 16 <= C) {                                        // an odd number of 16-channel batches: v holds the last one
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s = s + v[u];
+            c += 16;
+        }
+        for (; c < C; ++c) s = s + col[c * LN_TOK];
         const float mean = s / (float)C;
         float var = 0.0f;
         c = 0;
-        for (; c + 16 <= C; c += 16) {
-            float v[16];
+        if (C >= 16) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = tile[(c + u) * LN_TOK + tid];
+            for (int u = 0; u < 16; ++u) v[u] = col[u * LN_TOK];
+        }
+        for (; c + 32 <= C; c += 32) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = col[(c + 16 + u) * LN_TOK];
 #pragma unroll
             for (int u = 0; u < 16; ++u) { const float d = v[u] - mean; var = dfma(d, d, var); }
+            if (c + 48 <= C) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = col[(c + 32 + u) * LN_TOK];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const float d = w[u] - mean; var = dfma(d, d, var); }
         }
-        for (; c < C; ++c) { const float d = tile[c * LN_TOK + tid] - mean; var = dfma(d, d, var); }
+        if (c + 16 <= C) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const float d = v[u] - mean; var = dfma(d, d, var); }
+            c += 16;
+        }
+        for (; c < C; ++c) { const float d = col[c * LN_TOK] - mean; var = dfma(d, d, var); }
         mean_s[tid] = mean;
         rstd_s[tid] = 1.0f / __builtin_sqrtf(var / (float)C + eps);
     }

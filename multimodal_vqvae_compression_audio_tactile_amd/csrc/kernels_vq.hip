@@ -475,6 +475,83 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_token_kernel(
     if (q_out && tid < D) q_out[((size_t)b * D + tid) * T + t] = qs[tid];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Latency form, round 5: ONE BLOCK PER TOKEN, ONE THREAD PER CODE (K <= 512), the code row held in REGISTERS.
+// profiles/r05_kernel_stats_B1_encode_before.csv: the form above costs 67 us per 16-token chunk -- 8.4 us per book, of which the
+// 96-step chains are ~0.4: the rest is each thread walking two 384-byte rows with at most four loads in flight, then a dependent
+// gather of the winner's row.  Here a thread fetches its whole row (DV 16-byte loads, all in flight) one BOOK AHEAD -- the rows do
+// not depend on the residual, only the scores do -- so a book costs its chains, one arg-max and the update; the winner publishes
+// the row it already holds (no gather).  Same chains as every other form: dot = sum_d r_d e_d and hs = sum_d e_d^2, d ascending
+// from +0; score = dot - 0.5 hs; strict '>' over ascending codes, lowest index on ties.
+// ------------------------------------------------------------------------------------------------
+template <int DV>                                       // 16-byte pieces per code row: D = 4 DV
+__global__ __launch_bounds__(512) void rvq_ema_forward_rows_kernel(
+    const float* __restrict__ z, const float* __restrict__ books, float* __restrict__ q_out,
+    int32_t* __restrict__ idx_out, int B, int T, int nb, int K, int update_residual)
+{
+    constexpr int D = 4 * DV;
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float res[D], qs[D], qrow[D];
+    __shared__ float ws[8];
+    __shared__ int wi[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x, N = B * T;
+    const int b = n / T, t = n - b * T;
+    const bool has = tid < K;
+    if (tid < D) { res[tid] = z[((size_t)b * D + tid) * T + t]; qs[tid] = 0.0f; }
+    v4 e0[DV], e1[DV];
+    auto fetch = [&](v4 (&e)[DV], int bk) __attribute__((always_inline)) {
+        const float* row = books + ((size_t)bk * K + (has ? tid : 0)) * D;
+#pragma unroll
+        for (int u = 0; u < DV; ++u) e[u] = *reinterpret_cast<const v4*>(row + 4 * u);
+    };
+    auto book = [&](const v4 (&e)[DV], int bk) __attribute__((always_inline)) {
+        __syncthreads();                                           // res of this book is in place
+        float bs = -__builtin_inff(); int bi = 0x7fffffff;
+        if (has) {
+            float dot = 0.0f, hs = 0.0f;
+#pragma unroll
+            for (int u = 0; u < DV; ++u) {
+                const v4 r = *reinterpret_cast<const v4*>(res + 4 * u);        // every lane the same address: one broadcast read
+                dot = dfma(r.x, e[u].x, dot); dot = dfma(r.y, e[u].y, dot); dot = dfma(r.z, e[u].z, dot); dot = dfma(r.w, e[u].w, dot);
+                hs = dfma(e[u].x, e[u].x, hs); hs = dfma(e[u].y, e[u].y, hs); hs = dfma(e[u].z, e[u].z, hs); hs = dfma(e[u].w, e[u].w, hs);
+            }
+            const float sc = dot - 0.5f * hs;
+            if (sc > bs) { bs = sc; bi = tid; }
+        }
+        wave_argmax(bs, bi);
+        if (lane == 0) { ws[wave] = bs; wi[wave] = bi; }
+        __syncthreads();
+        float cs = ws[0]; int id = wi[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) amax_combine(cs, id, ws[w], wi[w]);
+        if (id < 0 || id >= K) id = 0;                             // all-NaN scores: defined, in-range code
+        if (tid == id) {
+#pragma unroll
+            for (int u = 0; u < DV; ++u) *reinterpret_cast<v4*>(qrow + 4 * u) = e[u];
+        }
+        __syncthreads();
+        if (tid < D) {
+            const float q = qrow[tid];
+            const float r = res[tid];
+            qs[tid] = (qs[tid] + (q - r)) + r;
+            if (update_residual) res[tid] = r - q;
+        }
+        if (idx_out && tid == 0) idx_out[(size_t)bk * N + n] = id;
+    };
+    if (nb > 0) fetch(e0, 0);
+    for (int bk = 0; bk < nb; bk += 2) {
+        if (bk + 1 < nb) fetch(e1, bk + 1);                        // in flight across this book's chains and arg-max
+        book(e0, bk);
+        if (bk + 1 < nb) {
+            if (bk + 2 < nb) fetch(e0, bk + 2);
+            book(e1, bk + 1);
+        }
+    }
+    __syncthreads();
+    if (q_out && tid < D) q_out[((size_t)b * D + tid) * T + t] = qs[tid];
+}
+
 hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_out, int32_t* idx_out,
                                   int B, int D, int T, int nb, int K, int update_residual, hipStream_t s)
 {
@@ -486,6 +563,10 @@ hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_o
         if (o) mvq::note_env_override(0x400 /* MVQ_BF_ENV_NO_TOKEN_RVQ */);
         return o;
     }();
+    if (N <= 256 && D == 96 && K <= 512 && (reinterpret_cast<uintptr_t>(books) & 15) == 0 && !no_token_form) {   // CODE_DIM = 96 (Training/...5.py:68)
+        hipLaunchKernelGGL(rvq_ema_forward_rows_kernel<24>, dim3(N), dim3(512), 0, s, z, books, q_out, idx_out, B, T, nb, K, update_residual);
+        return hipGetLastError();
+    }
     if (N <= 256 && D % 4 == 0 && D <= 128 && !no_token_form) {
         hipLaunchKernelGGL(rvq_ema_forward_token_kernel, dim3(N), dim3(256), 0, s, z, books, q_out, idx_out, B, D, T, nb, K, update_residual);
         return hipGetLastError();
@@ -840,6 +921,165 @@ hipError_t launch_dac_rvq_prepare(const float* cb, float* cbn, float* cn2, int n
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Latency form of the DAC quantiser (round 5): 128 THREADS PER TOKEN, two tokens per block, nothing staged in LDS.
+// profiles/r05_kernel_stats_B1_encode_before.csv: dac_rvq_kernel takes 598 us for the 75 tokens of one segment -- 19 us per stage on
+// 5 of the 256 CUs: a block copies ~100 KB of stage weights and codebook into LDS per stage, and a thread then walks 8 in_proj
+// chains of 64, 64 codes and 64 out_proj channels one after another.  The contract fixes the CHAINS (in_proj: 16 block partials of
+// C/16 channels per codebook dimension, added in block order; out_proj: an 8-long chain per channel; scores: an 8-long chain per
+// code), not who runs them: here a token's 128 threads take ONE partial chain, K/128 codes and C/128 channels each, straight from
+// global memory (L2-resident: every block reads the same 100 KB per stage), with every row a stage needs requested ahead of
+// the phase that uses it -- the next stage's in_proj rows before this stage's out_proj, the code rows (normalised for the search,
+// raw for the straight-through value) and out_proj rows at the top of the stage -- so no phase starts by waiting for L2, and
+// the winner publishes the raw row it already holds.  Needs the prepared codebook (mvq_dac_rvq_prepare_f32).
+// LDS: res[2][C] | part[2][16][8] | ze[2][8] | pre[2][8] | red
+// ------------------------------------------------------------------------------------------------
+template <int CPT, int KJ>    // C = 16 * CPT channels, K = 128 * KJ codes, Dc = 8
+__global__ __launch_bounds__(256) void dac_rvq_lat_kernel(
+    const float* __restrict__ z, const float* __restrict__ in_w, const float* __restrict__ in_b,
+    const float* __restrict__ cb, const float* __restrict__ out_w, const float* __restrict__ out_b,
+    float* __restrict__ zq, int32_t* __restrict__ codes, float* __restrict__ latents,
+    const int32_t* __restrict__ nq_item, int B, int T, int nq,
+    const float* __restrict__ cbn_pre, const float* __restrict__ cn2_pre)
+{
+    constexpr int C = 16 * CPT, Dc = 8, K = 128 * KJ, CO = C / 128, IV = CPT / 4;
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float res_s[2][C];
+    __shared__ float part[2][16][Dc], ze[2][Dc], pre[2][Dc], red_s[2][2];
+    __shared__ int red_i[2][2];
+    const int tid = threadIdx.x, tl = tid & 127, tk = tid >> 7, lane = tid & 63, wv = (tid >> 6) & 1;
+    const int N = B * T;
+    const int n = blockIdx.x * 2 + tk;
+    const bool live = n < N;
+    const int bb = live ? n / T : 0, tt = live ? n - bb * T : 0;
+    const int lim = (nq_item && live) ? nq_item[bb] : nq;
+    const int g = tl >> 3, d_in = tl & 7;                          // in_proj role: block partial g of codebook dimension d_in
+    const int c0 = tl * CO;                                        // out_proj role: channels c0 .. c0 + CO - 1
+
+    float resr[CO], acc[CO];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) {
+        acc[j] = 0.0f;
+        resr[j] = live ? z[((size_t)bb * C + c0 + j) * T + tt] : 0.0f;
+        res_s[tk][c0 + j] = resr[j];
+    }
+    v4 iw[IV];                                                     // in_proj row piece of (stage, d_in, block g): CPT floats
+    auto fetch_in = [&](int st) __attribute__((always_inline)) {
+        const float* wr = in_w + ((size_t)st * Dc + d_in) * C + g * CPT;
+#pragma unroll
+        for (int u = 0; u < IV; ++u) iw[u] = *reinterpret_cast<const v4*>(wr + 4 * u);
+    };
+    fetch_in(0);
+    for (int st = 0; st < nq; ++st) {
+        // rows this stage needs later, requested now: codes k = tl + 128 j (normalised + raw + squared norm), out_proj rows + bias
+        v4 sw[KJ][2], rw[KJ][2], ow[CO][2];
+        float cn2v[KJ], obv[CO];
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+            const size_t k = (size_t)st * K + tl + 128 * j;
+            sw[j][0] = *reinterpret_cast<const v4*>(cbn_pre + k * Dc); sw[j][1] = *reinterpret_cast<const v4*>(cbn_pre + k * Dc + 4);
+            rw[j][0] = *reinterpret_cast<const v4*>(cb + k * Dc); rw[j][1] = *reinterpret_cast<const v4*>(cb + k * Dc + 4);
+            cn2v[j] = cn2_pre[k];
+        }
+#pragma unroll
+        for (int j = 0; j < CO; ++j) {
+            const float* wr = out_w + ((size_t)st * C + c0 + j) * Dc;
+            ow[j][0] = *reinterpret_cast<const v4*>(wr); ow[j][1] = *reinterpret_cast<const v4*>(wr + 4);
+            obv[j] = out_b[(size_t)st * C + c0 + j];
+        }
+        __syncthreads();                                           // res_s holds this stage's residual
+        {   // in_proj block partial: channels g*CPT .. +CPT-1 ascending, from +0
+            const float* rr = &res_s[tk][g * CPT];
+            float p = 0.0f;
+#pragma unroll
+            for (int u = 0; u < IV; ++u) {
+                const v4 r4 = *reinterpret_cast<const v4*>(rr + 4 * u);
+                p = dfma(iw[u].x, r4.x, p); p = dfma(iw[u].y, r4.y, p); p = dfma(iw[u].z, r4.z, p); p = dfma(iw[u].w, r4.w, p);
+            }
+            part[tk][g][d_in] = p;
+        }
+        if (st + 1 < nq) fetch_in(st + 1);                         // next stage's in_proj rows: in flight across search and out_proj
+        __syncthreads();
+        if (tl < Dc) {                                             // the 16 block partials in block order, + bias
+            float a = part[tk][0][tl];
+#pragma unroll
+            for (int gg = 1; gg < 16; ++gg) a = a + part[tk][gg][tl];
+            const float v = a + in_b[(size_t)st * Dc + tl];
+            ze[tk][tl] = v;
+            if (live) latents[((size_t)bb * nq * Dc + (size_t)st * Dc + tl) * T + tt] = v;
+        }
+        __syncthreads();
+        float bs = -__builtin_inff(); int bi = 0x7fffffff;
+        {   // F.normalize over Dc (every thread of the token computes the same values), then this thread's codes, ascending
+            float ss = 0.0f;
+#pragma unroll
+            for (int d = 0; d < Dc; ++d) { const float v = ze[tk][d]; ss = dfma(v, v, ss); }
+            const float den = __builtin_fmaxf(__builtin_sqrtf(ss), 1e-12f);
+            float s2 = 0.0f, ev[Dc];
+#pragma unroll
+            for (int d = 0; d < Dc; ++d) { ev[d] = ze[tk][d] / den; s2 = dfma(ev[d], ev[d], s2); }
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
+                float dot = 0.0f;
+                dot = dfma(ev[0], sw[j][0].x, dot); dot = dfma(ev[1], sw[j][0].y, dot); dot = dfma(ev[2], sw[j][0].z, dot); dot = dfma(ev[3], sw[j][0].w, dot);
+                dot = dfma(ev[4], sw[j][1].x, dot); dot = dfma(ev[5], sw[j][1].y, dot); dot = dfma(ev[6], sw[j][1].z, dot); dot = dfma(ev[7], sw[j][1].w, dot);
+                const float dist = (s2 - 2.0f * dot) + cn2v[j];
+                const float sc = -dist;
+                if (sc > bs) { bs = sc; bi = tl + 128 * j; }
+            }
+        }
+        wave_argmax(bs, bi);                                       // a wave holds 64 threads of ONE token
+        if (lane == 0) { red_s[tk][wv] = bs; red_i[tk][wv] = bi; }
+        __syncthreads();
+        {
+            float cs = red_s[tk][0]; int id = red_i[tk][0];
+            amax_combine(cs, id, red_s[tk][1], red_i[tk][1]);
+            if (id < 0 || id >= K) id = 0;
+            if (tl == (id & 127)) {                                // the thread that holds the winning code's raw row
+                const int jw = id >> 7;
+                v4 r0 = rw[0][0], r1 = rw[0][1];
+#pragma unroll
+                for (int j = 1; j < KJ; ++j) if (j == jw) { r0 = rw[j][0]; r1 = rw[j][1]; }
+                const float raw[Dc] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+                for (int d = 0; d < Dc; ++d) { const float zv = ze[tk][d]; pre[tk][d] = zv + (raw[d] - zv); }
+                if (live) codes[((size_t)bb * nq + st) * T + tt] = id;
+            }
+        }
+        __syncthreads();
+        {   // out_proj: an 8-long chain per owned channel, + bias; accumulate (under the item's stage limit) and update the residual
+            float pv[Dc];
+#pragma unroll
+            for (int d = 0; d < Dc; ++d) pv[d] = pre[tk][d];
+#pragma unroll
+            for (int j = 0; j < CO; ++j) {
+                float a = 0.0f;
+                a = dfma(ow[j][0].x, pv[0], a); a = dfma(ow[j][0].y, pv[1], a); a = dfma(ow[j][0].z, pv[2], a); a = dfma(ow[j][0].w, pv[3], a);
+                a = dfma(ow[j][1].x, pv[4], a); a = dfma(ow[j][1].y, pv[5], a); a = dfma(ow[j][1].z, pv[6], a); a = dfma(ow[j][1].w, pv[7], a);
+                const float zqi = a + obv[j];
+                if (st < lim) acc[j] = acc[j] + zqi;
+                resr[j] = resr[j] - zqi;
+                res_s[tk][c0 + j] = resr[j];
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < CO; ++j) zq[((size_t)bb * C + c0 + j) * T + tt] = acc[j];
+    }
+}
+
+template <int CPT>
+static hipError_t launch_dac_rvq_lat_t(const float* z, const float* in_w, const float* in_b, const float* cb,
+                                       const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
+                                       const int32_t* nq_item, int B, int T, int nq, hipStream_t s, const float* cbn_pre, const float* cn2_pre)
+{
+    const int N = B * T;
+    hipLaunchKernelGGL((dac_rvq_lat_kernel<CPT, 8>), dim3((N + 1) / 2), dim3(256), 0, s,
+                       z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, cbn_pre, cn2_pre);
+    return hipGetLastError();
+}
+
 template <int CPT, int DC>
 static hipError_t launch_dac_rvq_t(const float* z, const float* in_w, const float* in_b, const float* cb,
                                    const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
@@ -863,6 +1103,17 @@ hipError_t launch_dac_rvq(const float* z, const float* in_w, const float* in_b, 
 {
     if (B * T == 0) return hipSuccess;
     if (Dc != 8) return hipErrorInvalidValue;
+    // a handful of tokens (one segment is 75, the reference's batch of six 450): the latency form, two tokens per block
+    static const bool no_lat = [] { const bool o = getenv("MVQ_NO_DAC_RVQ_LAT") != nullptr; if (o) mvq::note_env_override(0x2000); return o; }();
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in_w) | reinterpret_cast<uintptr_t>(out_w) | reinterpret_cast<uintptr_t>(cb) |
+                           reinterpret_cast<uintptr_t>(cbn_pre)) & 15) == 0;
+    if (B * T <= 1024 && K == 1024 && cbn_pre && cn2_pre && aligned && !no_lat) {
+        switch (C) {
+            case 1024: return launch_dac_rvq_lat_t<64>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, s, cbn_pre, cn2_pre);
+            case 512:  return launch_dac_rvq_lat_t<32>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, s, cbn_pre, cn2_pre);
+            case 256:  return launch_dac_rvq_lat_t<16>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, s, cbn_pre, cn2_pre);
+        }
+    }
     switch (C) {
         case 1024: return launch_dac_rvq_t<64, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K, s, cbn_pre, cn2_pre);
         case 512:  return launch_dac_rvq_t<32, 8>(z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, K, s, cbn_pre, cn2_pre);

@@ -38,4 +38,9 @@ def dev():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
+    if os.environ.get("MVQ_TEST_POISON") == "1":
+        # every torch.empty() comes back filled with NaN: a kernel that reads an element its producer never wrote (a tile tail, a
+        # padded column) then shows up as a NaN / a mismatch instead of depending on what the caching allocator last kept there
+        torch.utils.deterministic.fill_uninitialized_memory = True
+        torch.use_deterministic_algorithms(True, warn_only=True)
     return torch.device("cuda:0")

@@ -227,6 +227,12 @@ def test_dac_rvq_bit_exact(B, T, nq, orc, dev):
     assert np.array_equal(codes.cpu().numpy(), want_codes)
     assert np.array_equal(lat.cpu().numpy(), want_lat)
     assert np.array_equal(zq.cpu().numpy(), want_zq)
+    # with the prepared codebook (what the modules pass) a handful of tokens takes the latency form (128 threads per token)
+    prep = ops.dac_rvq_prepare(_t(cb, dev))
+    zq, codes, lat = ops.dac_rvq(_t(z, dev), _t(in_w, dev), _t(in_b, dev), _t(cb, dev), _t(out_w, dev), _t(out_b, dev), nq, prepared=prep)
+    assert np.array_equal(codes.cpu().numpy(), want_codes)
+    assert np.array_equal(lat.cpu().numpy(), want_lat)
+    assert np.array_equal(zq.cpu().numpy(), want_zq)
 
 
 def test_layernorm_attention_gelu_bit_exact(orc, dev):
