@@ -36,7 +36,8 @@ extern "C" {
 #define MVQ_ACT_TANH 1
 #define MVQ_ACT_GELU 2   /* exact-erf GELU (nn.GELU() of CrossPredictor.ffn); MFMA-tiled, non-transposed shapes only */
 
-/* ABI version.  2 (round 4): mvq_rvq_ema_step_f32 takes the larger 16-byte-aligned scratch that
+/* ABI version.  3 (round 5): whole-stack entry points (mvq_encoder_fwd_f32, mvq_decoder_fwd_f32, mvq_decoder_fwd_saving_f32,
+ * mvq_decoder_bwd_input_f32 and the mvq_stack handle).  2 (round 4): mvq_rvq_ema_step_f32 takes the larger 16-byte-aligned scratch that
  * mvq_rvq_ema_step_scratch_bytes() reports (version 1 documented nb*B*T int32), mvq_profile_end2() reports truncation,
  * mvq_build_flags() exists. */
 int mvq_abi_version(void);
@@ -456,6 +457,53 @@ int mvq_adamw_f32(float* p, const float* g, float* m, float* v, const float* cli
 
 /* out = g * (1 - y*y): backward of the decoder's final tanh (y = saved output). */
 int mvq_mul_dtanh_f32(const float* g, const float* y, float* out, size_t n, void* stream);
+
+/* ---- whole stacks (encoder_fwd, decoder_fwd, decoder_bwd_input) ------------------------------------------
+ * One call per stack instead of one per layer: `A_ENC(a)` / `T_ENC(t)` (Training/compare_dacvsproposal_5.py:294,296), `T_DEC(z)`
+ * (...:322) and the gradient of T_DEC w.r.t. its input under `scaler.scale(total).backward()` (...:393; weights frozen, ...:283-284).
+ *
+ * A stack handle holds the launch plan and pointers into a caller-provided WEIGHTS BLOB in which mvq_*_create folds the weight norm
+ * and packs every conv once (for a decoder also the input-gradient images), next to copies of the biases and Snake alphas.  The
+ * parameters are handed over as device pointers in the order mvq_stack_param_info() reports -- upstream `dac` state-dict names
+ * ("block.1.block.0.block.1.weight_v", "model.3.block.1.bias", ...) with their shapes -- so any caller that can read a checkpoint
+ * can bind them; they are not referenced after create returns.  create with params == NULL and weights_blob == NULL makes a
+ * description-only handle (param_info / weights_bytes / out_len / workspace queries work, fwd does not).
+ *
+ * A forward / backward call walks the plan the Python mirror used to hold: dual outputs (a producer also emits the Snake its wide
+ * consumer needs), one fused launch per ResidualUnit of width 64 / 96 / 128, zero-padded rows where a length is not a multiple of
+ * 4, and at throughput batch sizes the virtually packed (encoder tail) / packed (decoder head) latent-rate rows.  Intermediates
+ * live in a caller-provided WORKSPACE (mvq_*_workspace_bytes, laid out by a deterministic first-fit arena); nothing is allocated
+ * or synchronised, so a call can be captured into a hipGraph.  Results are bit-identical to the per-layer entry points above
+ * (tests/test_gpu_stacks.py) and to oracle/c/oracle.c.
+ *
+ *   mvq_encoder_fwd_f32        x[batch, 1, t]            -> z[batch, d_latent, mvq_encoder_out_len(t)]
+ *   mvq_decoder_fwd_f32        z[batch, input_channel, t] -> y[batch, d_out, mvq_decoder_out_len(t)]  (tanh applied)
+ *   mvq_decoder_fwd_saving_f32 the same values, keeping every Snake input and the output in `saved` (mvq_decoder_saved_bytes)
+ *   mvq_decoder_bwd_input_f32  gz[batch, input_channel, t] = dL/dz from gy = dL/dy and `saved`: the same MFMA conv kernels on flipped /
+ *                              transposed weight images with the Snake and tanh derivatives in their epilogues (bit-identical to
+ *                              mvq_conv1d_dgrad_f32 layer by layer)
+ * mvq_stack_set_plan: batch thresholds of the packed latent-rate forms (0 = keep; defaults 32 / 32) -- A/B measurements only. */
+typedef struct mvq_stack mvq_stack;
+typedef struct mvq_encoder_desc { int d_model; int n_strides; int strides[8]; int d_latent; } mvq_encoder_desc;     /* dac Encoder(64, [2,4,5,8], 1024) */
+typedef struct mvq_decoder_desc { int input_channel; int channels; int n_rates; int rates[8]; int d_out; int output_padding; } mvq_decoder_desc;
+int mvq_encoder_create(mvq_stack** out, const mvq_encoder_desc* desc, const float* const* params, void* weights_blob, size_t blob_bytes, void* stream);
+int mvq_decoder_create(mvq_stack** out, const mvq_decoder_desc* desc, const float* const* params, void* weights_blob, size_t blob_bytes, void* stream);
+void mvq_stack_destroy(mvq_stack* s);
+int mvq_stack_param_count(const mvq_stack* s);
+int mvq_stack_param_info(const mvq_stack* s, int i, char* name, int name_len, int* dims3);
+size_t mvq_stack_weights_bytes(const mvq_stack* s);
+int mvq_stack_set_plan(mvq_stack* s, int vpack_min_batch, int pack_min_batch);
+int mvq_encoder_out_len(const mvq_stack* s, int t);
+size_t mvq_encoder_workspace_bytes(const mvq_stack* s, int batch, int t);
+int mvq_encoder_fwd_f32(const mvq_stack* s, const float* x, float* z, void* workspace, size_t workspace_bytes, int batch, int t, void* stream);
+int mvq_decoder_out_len(const mvq_stack* s, int t);
+size_t mvq_decoder_workspace_bytes(const mvq_stack* s, int batch, int t);      /* covers fwd, fwd_saving and bwd_input */
+int mvq_decoder_fwd_f32(const mvq_stack* s, const float* z, float* y, void* workspace, size_t workspace_bytes, int batch, int t, void* stream);
+size_t mvq_decoder_saved_bytes(const mvq_stack* s, int batch, int t);
+int mvq_decoder_fwd_saving_f32(const mvq_stack* s, const float* z, float* y, void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                               int batch, int t, void* stream);
+int mvq_decoder_bwd_input_f32(const mvq_stack* s, const void* saved, size_t saved_bytes, const float* gy, float* gz, void* workspace,
+                              size_t workspace_bytes, int batch, int t, void* stream);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,12 @@ int hipfail(hipError_t e, const char* what)
     return fail(MVQ_EHIP, "%s: %s", what, hipGetErrorString(e));
 }
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+}  // namespace
+namespace mvq {
+// stacks.hip reports through the same mvq_last_error() text
+void set_last_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+}
+namespace {
 inline int conv_out_len(int tin, int ks, int stride, int dil, int pad)
 {
     const int span = tin + 2 * pad - dil * (ks - 1) - 1;
@@ -155,7 +161,7 @@ int mvq_profile_end2(mvq_profile_entry* out, int max_entries, int* n_entries, in
     return MVQ_OK;
 }
 
-int mvq_abi_version(void) { return 2; }
+int mvq_abi_version(void) { return 3; }
 unsigned mvq_build_flags(void)
 {
     /* every conv translation unit is compiled with the same flags (one Makefile rule); also peek at the environment knobs so
