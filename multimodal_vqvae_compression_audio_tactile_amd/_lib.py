@@ -17,6 +17,16 @@ import os as _os
 SO_PATH = Path(_os.environ["MVQ_LIB_PATH"]).resolve() if _os.environ.get("MVQ_LIB_PATH") else _PKG / "libmvq_hip.so"
 _lib = None
 
+class EncoderDesc(ctypes.Structure):
+    """mvq_encoder_desc (include/mvq.h)."""
+    _fields_ = [("d_model", c_int), ("n_strides", c_int), ("strides", c_int * 8), ("d_latent", c_int)]
+
+
+class DecoderDesc(ctypes.Structure):
+    """mvq_decoder_desc (include/mvq.h)."""
+    _fields_ = [("input_channel", c_int), ("channels", c_int), ("n_rates", c_int), ("rates", c_int * 8), ("d_out", c_int), ("output_padding", c_int)]
+
+
 class ProfileEntry(ctypes.Structure):
     """mvq_profile_entry (include/mvq.h)."""
     _fields_ = [("kernel", ctypes.c_char * 96), ("seconds", ctypes.c_double), ("flops", ctypes.c_double), ("launches", c_int)]
@@ -103,6 +113,23 @@ EXPORTS = {
     "mvq_gelu_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvq_sub3d_f32": (c_int, [c_void_p, c_size_t, c_size_t] * 3 + [c_int] * 3 + [c_void_p]),
     "mvq_copy3d_f32": (c_int, [c_void_p, c_size_t, c_size_t] * 2 + [c_int] * 3 + [c_void_p]),
+    # whole stacks (ABI 3)
+    "mvq_encoder_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(EncoderDesc), ctypes.POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
+    "mvq_decoder_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(DecoderDesc), ctypes.POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
+    "mvq_stack_destroy": (None, [c_void_p]),
+    "mvq_stack_param_count": (c_int, [c_void_p]),
+    "mvq_stack_param_info": (c_int, [c_void_p, c_int, c_char_p, c_int, ctypes.POINTER(c_int)]),
+    "mvq_stack_weights_bytes": (c_size_t, [c_void_p]),
+    "mvq_stack_set_plan": (c_int, [c_void_p, c_int, c_int]),
+    "mvq_encoder_out_len": (c_int, [c_void_p, c_int]),
+    "mvq_encoder_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "mvq_encoder_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "mvq_decoder_out_len": (c_int, [c_void_p, c_int]),
+    "mvq_decoder_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "mvq_decoder_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "mvq_decoder_saved_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "mvq_decoder_fwd_saving_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "mvq_decoder_bwd_input_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
 }
 
 
@@ -151,4 +178,6 @@ def build_flags() -> int:
 def check(status: int, what: str) -> None:
     if status != 0:
         msg = lib().mvq_last_error()
-        raise MvqError(f"{what} failed ({status}): {msg.decode() if msg else ''}")
+        err = MvqError(f"{what} failed ({status}): {msg.decode() if msg else ''}")
+        err.status = status                       # MVQ_EINVAL -1 | MVQ_EUNSUPPORTED -2 | MVQ_EHIP -3 (include/mvq.h)
+        raise err

@@ -31,6 +31,18 @@ from ._lib import MvqError
 ENC_RATES = (2, 4, 5, 8)
 DEC_RATES = (8, 5, 4, 2)
 
+# A/B switches of the launch plan, read ONCE at import (never per call) and reported by bench.py as `plan_overrides`; any of them
+# (or an opt-in arithmetic mode, ops.set_arith) routes Encoder / Decoder through the per-layer Python plan below instead of the
+# whole-stack C entry points (mvq_encoder_fwd_f32 / mvq_decoder_fwd_f32 / mvq_decoder_bwd_input_f32), whose plan is the library's.
+PLAN_ENV = ("MVQ_RU_PRESNAKED", "MVQ_VPACKED_LATENTS", "MVQ_PACKED_MIN_BATCH", "MVQ_PACKED_LATENTS", "MVQ_PY_PLAN")
+PLAN_OVERRIDES = {k: os.environ[k] for k in PLAN_ENV if k in os.environ}
+USE_STACKS = not PLAN_OVERRIDES            # tests flip this to compare the two plans
+
+
+def plan_overrides():
+    """Names of the launch-plan / arithmetic A/B switches seen in the environment at import (empty in a product run)."""
+    return sorted(PLAN_OVERRIDES) + sorted(ops.ARITH_ENV_SEEN)
+
 
 class _Packed:
     """Cache of derived device tensors keyed on the (identity, version, storage) of their source parameters.
@@ -213,7 +225,7 @@ class ResidualUnit(nn.Module):
     # C = 96.  At C = 64 the extra Snake of the dual output and the second output tensor cost more than the staging saves
     # (89.7-96.2 vs 99.2-106.9 TFLOP/s, gpurun_out/r3e), so those units keep Snake-on-load.
     # MVQ_RU_PRESNAKED=0 / =all: never / always for the fused widths (A/B runs).
-    PRESNAKED_MIN_C = {"0": 129, "all": 1}.get(os.environ.get("MVQ_RU_PRESNAKED", ""), 65)
+    PRESNAKED_MIN_C = {"0": 129, "all": 1}.get(PLAN_OVERRIDES.get("MVQ_RU_PRESNAKED", ""), 65)
 
     def wants_presnaked(self) -> bool:
         return self.block[1].cin >= self.PRESNAKED_MIN_C
@@ -257,7 +269,11 @@ class EncoderBlock(nn.Module):
             geo = ops.vpacked_geometry(x.shape[-1], x.shape[-1], down.ks, down.stride, down.dilation, down.padding, follow_pad=vpack[1])
             if geo is not None and alpha_dual is None and down.cin % 32 == 0 and down.cout % 128 == 0:
                 tout, tout_rows, _ = geo
-                return down.run_vpacked(x, vpack[0], x.shape[-1], tout_rows, alpha_out=alpha_next), tout
+                try:
+                    return down.run_vpacked(x, vpack[0], x.shape[-1], tout_rows, alpha_out=alpha_next), tout
+                except MvqError as e:              # no LDS-DMA / regular-epilogue form for this shape (e.g. MVQ_NO_DMA=1): the plain launch
+                    if getattr(e, "status", None) != -2:
+                        raise
             return down.run(x, alpha_out=alpha_next, alpha_dual=alpha_dual), None
         return down.run(x, alpha_out=alpha_next, alpha_dual=alpha_dual)
 
@@ -274,6 +290,7 @@ class Encoder(nn.Module):
 
     def __init__(self, d_model: int = 64, strides=ENC_RATES, d_latent: int = 1024):
         super().__init__()
+        self._desc = (int(d_model), tuple(int(s) for s in strides), int(d_latent))
         layers: List[nn.Module] = [WNConv1d(1, d_model, 7, padding=3)]
         for s in strides:
             d_model *= 2
@@ -281,9 +298,25 @@ class Encoder(nn.Module):
         layers += [Snake1d(d_model), WNConv1d(d_model, d_latent, 3, padding=1)]
         self.block = nn.Sequential(*layers)
         self.enc_dim = d_model
+        self._stack_cache = _Packed()
+
+    def stack(self):
+        """The mvq_stack of this encoder (include/mvq.h): weights folded and packed once per parameter version."""
+        named = dict(self.named_parameters())
+        probe = ops.Stack.encoder(*self._desc)
+        params = [named[n] for n in probe.param_names()]
+        return self._stack_cache.get(params, lambda: probe.bind(params))
 
     @torch.no_grad()
     def forward(self, x):
+        """A_ENC(a) / T_ENC(t) (Training/compare_dacvsproposal_5.py:294,296): ONE C call, mvq_encoder_fwd_f32."""
+        if USE_STACKS and ops.get_arith() == "f32" and x.is_cuda:
+            return self.stack().encoder_fwd(x)
+        return self.forward_plan(x)
+
+    @torch.no_grad()
+    def forward_plan(self, x):
+        """The same launch plan walked from Python over the per-layer entry points (the opt-in arithmetic modes and A/B runs)."""
         n = len(self.block)
         a1 = self.block[1].first_alpha()                            # first unit wants a pre-snaked input: dual output of the 1 -> 64 conv
         out = self.block[0].run(x, alpha_dual=a1)
@@ -312,7 +345,7 @@ class Encoder(nn.Module):
     # 128 x 96 tile per item, 78 % live) -- with no repacked copy in memory.  MVQ_VPACKED_LATENTS=0 switches it off (A/B runs).
     VPACK_SEG = 10
     VPACK_MIN_BATCH = 32
-    VPACKED = os.environ.get("MVQ_VPACKED_LATENTS", "1") != "0"
+    VPACKED = PLAN_OVERRIDES.get("MVQ_VPACKED_LATENTS", "1") != "0"
 
     def _vpack(self, batch, tail):
         if not self.VPACKED or batch < self.VPACK_MIN_BATCH:
@@ -378,11 +411,26 @@ class Decoder(nn.Module):
             layers.append(DecoderBlock(inp, out, s, output_padding))
         layers += [Snake1d(out), WNConv1d(out, d_out, 7, padding=3), nn.Tanh()]
         self.model = nn.Sequential(*layers)
+        self._desc = (int(input_channel), int(channels), tuple(int(r) for r in rates), int(d_out), bool(output_padding))
+        self._stack_cache = _Packed()
+
+    def stack(self):
+        """The mvq_stack of this decoder (forward + input-gradient images), made once per parameter version."""
+        named = dict(self.named_parameters())
+        probe = ops.Stack.decoder(*self._desc)
+        params = [named[n] for n in probe.param_names()]
+        return self._stack_cache.get(params, lambda: probe.bind(params))
+
+    def _stacked(self, z) -> bool:
+        return USE_STACKS and ops.get_arith() == "f32" and z.is_cuda and z.shape[0] > 0 and z.shape[-1] > 0
 
     # ---- training config (SURVEY.md section 8f, row f1): gradient w.r.t. the input, weights frozen ---------------
     @torch.no_grad()
     def forward_saving(self, z):
         """Same arithmetic as forward(), but every Snake input (and the final tanh output) is kept for the backward."""
+        if self._stacked(z):                                       # ONE C call: mvq_decoder_fwd_saving_f32
+            y, blob = self.stack().decoder_fwd_saving(z)
+            return y, {"blob": blob, "batch": z.shape[0], "z_len": z.shape[-1]}
         m = self.model
         nblk = len(m) - 4
         saved = {"z_len": z.shape[-1]}
@@ -407,6 +455,8 @@ class Decoder(nn.Module):
     def backward_input(self, saved, gy):
         """dL/dz from dL/dy: the same MFMA conv kernels on flipped / transposed weight images, Snake and tanh
         derivatives fused into their epilogues (83 GFLOP per segment, like the forward)."""
+        if "blob" in saved:                                        # ONE C call: mvq_decoder_bwd_input_f32
+            return self.stack().decoder_bwd_input(saved.pop("blob"), gy, saved["batch"], saved["z_len"])
         m = self.model
         nblk = len(m) - 4
         # every saved activation is released as soon as its layer's gradient has been queued (pop, not index): the backward's
@@ -439,6 +489,16 @@ class Decoder(nn.Module):
 
     @torch.no_grad()
     def _forward_fast(self, z):
+        """T_DEC(z) (Training/compare_dacvsproposal_5.py:322): ONE C call, mvq_decoder_fwd_f32."""
+        if self._stacked(z):
+            return self.stack().decoder_fwd(z)
+        if z.shape[-1] == 0:                                       # a clip shorter than a token: nothing to decode
+            return z.new_zeros(z.shape[0], self._desc[3], 0)
+        return self.forward_plan(z)
+
+    @torch.no_grad()
+    def forward_plan(self, z):
+        """The same launch plan walked from Python over the per-layer entry points (the opt-in arithmetic modes and A/B runs)."""
         m = self.model
         nblk = len(m) - 4
         # Rows whose length is not a multiple of 4 (75 latent frames, the 2 999-sample block) are carried zero-padded to the
@@ -465,8 +525,8 @@ class Decoder(nn.Module):
     # 78 %); the transposed conv writes the ordinary unpacked [B, C/2, 8T] tensor, everything behind it is unchanged.
     # MVQ_PACKED_LATENTS=0 switches it off (A/B runs).
     PACK_SEG = 8
-    PACK_MIN_BATCH = int(os.environ.get("MVQ_PACKED_MIN_BATCH", "32"))
-    PACKED = os.environ.get("MVQ_PACKED_LATENTS", "1") != "0"
+    PACK_MIN_BATCH = int(PLAN_OVERRIDES.get("MVQ_PACKED_MIN_BATCH", "32"))
+    PACKED = PLAN_OVERRIDES.get("MVQ_PACKED_LATENTS", "1") != "0"
 
     def _use_packed_latents(self, z) -> bool:
         m = self.model
@@ -516,7 +576,8 @@ class _DecoderInputGrad(torch.autograd.Function):
         # node -> ctx.saved -> y -> grad_fn -> node is a reference cycle only Python's cyclic collector can break -- the whole
         # saved forward (45 GB at 256 segments) then outlives the step until a full collection happens to run (measured:
         # +45 GB per step, 145 GB peak after three steps).  A detached alias shares the storage without the back pointer.
-        saved["y"] = y.detach()
+        if "blob" not in saved:
+            saved["y"] = y.detach()
         ctx.dec, ctx.saved = dec, saved
         return y
 

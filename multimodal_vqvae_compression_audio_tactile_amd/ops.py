@@ -160,7 +160,7 @@ def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x
     B, C, T = x.shape
     # the fused single-launch form, unless an opt-in arithmetic mode claims the unit's 7-tap conv (then: split + matrix-core conv +
     # the exact 1x1 with its skip, as for the wide units)
-    unfuse = w7q is not None and x_snaked is not None and os.environ.get("MVQ_ARITH_KEEP_FUSED") != "1"
+    unfuse = w7q is not None and x_snaked is not None and not _KEEP_FUSED
     if _lib.lib().mvq_residual_unit_scratch_floats(B, C, T, dil) == 0 and not unfuse:
         return residual_unit_fused(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next, alpha_dual, tvalid, x_snaked)
     if x_snaked is not None and w7q is not None:      # opt-in modes (set_arith): non-parity, fp32-class
@@ -177,6 +177,10 @@ def residual_unit(x, w7p, b7, alpha_a, alpha_b, w1p, b1, dil, alpha_next=None, x
 # 7-tap convs of the wide ResidualUnits (C a multiple of 128, or of 96: C = 192) through the three-piece bf16 split: fp32-accurate,
 # not bit-identical; everything else keeps the exact path.
 _ARITH = "f32"
+# A/B knobs of the opt-in modes, read ONCE at import and reported (dac.plan_overrides / bench.py `plan_overrides`)
+ARITH_ENV_SEEN = {k: os.environ[k] for k in ("MVQ_ARITH_KEEP_FUSED", "MVQ_BF16X6_NO96") if k in os.environ}
+_KEEP_FUSED = ARITH_ENV_SEEN.get("MVQ_ARITH_KEEP_FUSED") == "1"
+_NO96 = ARITH_ENV_SEEN.get("MVQ_BF16X6_NO96") == "1"
 
 
 def set_arith(mode: str) -> None:
@@ -190,10 +194,27 @@ def get_arith() -> str:
     return _ARITH
 
 
+class arith:
+    """``with ops.arith("f16x3"): ...`` -- an opt-in arithmetic mode for the duration of a block (restored on exit, also on an
+    exception).  The mode is process-global state read at LAUNCH time: a hipGraph captured under one mode keeps it when replayed."""
+
+    def __init__(self, mode: str):
+        self.mode, self.prev = mode, None
+
+    def __enter__(self):
+        self.prev = get_arith()
+        set_arith(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_arith(self.prev)
+        return False
+
+
 def bf16x6_eligible(c: int) -> bool:
     if _ARITH not in ("bf16x6", "f16x3") or c % 16 != 0:
         return False
-    if os.environ.get("MVQ_BF16X6_NO96") == "1":          # A/B knob: 128-row tiles only
+    if _NO96:                                             # A/B knob: 128-row tiles only
         return c % 128 == 0
     return c % 128 == 0 or c % 96 == 0
 
@@ -804,3 +825,146 @@ def mel_max_grad_(dM, dden, maxv, argm, B, nfr, eps):
     check(_lib.lib().mvq_mel_max_grad_f32(dden.data_ptr(), maxv.data_ptr(), argm.data_ptr(), dM.data_ptr(), B, nfr, float(eps),
                                           _stream()), "mvq_mel_max_grad_f32")
     return dM
+
+
+# ---------------------------------------------------------------------------------------- whole stacks (include/mvq.h, ABI 3)
+class Stack:
+    """mvq_stack handle of one dac Encoder / Decoder: launch plan + folded / packed weights in one device blob.
+
+    ``Stack.encoder(d_model, strides, d_latent)`` / ``Stack.decoder(input_channel, channels, rates, d_out, output_padding)`` make a
+    description-only handle (``param_names()`` lists the upstream state-dict keys it expects, in order); ``bind(tensors)`` makes
+    the working handle from the parameter tensors in that order.  ``encoder_fwd`` / ``decoder_fwd`` / ``decoder_fwd_saving`` /
+    ``decoder_bwd_input`` are ONE C call each (mvq_encoder_fwd_f32, ...): the per-layer plan lives in the library."""
+
+    _BY_ID = {}                      # torch.ops.mi355x_vqvae.encoder_fwd / decoder_fwd / decoder_bwd_input name a stack by this id
+
+    def __init__(self, kind, desc, handle, blob=None):
+        import weakref
+        self.kind, self.desc, self.handle, self.blob = kind, desc, handle, blob
+        self.id = id(self)
+        Stack._BY_ID[self.id] = weakref.ref(self)
+
+    @classmethod
+    def by_id(cls, i):
+        ref = cls._BY_ID.get(int(i))
+        st = ref() if ref else None
+        if st is None:
+            raise MvqError(f"no live Stack with id {i}")
+        return st
+
+    @classmethod
+    def _make(cls, kind, desc, params=None):
+        import ctypes
+        L = _lib.lib()
+        create = L.mvq_encoder_create if kind == "encoder" else L.mvq_decoder_create
+        h = ctypes.c_void_p()
+        if params is None:
+            check(create(ctypes.byref(h), ctypes.byref(desc), None, None, 0, None), f"mvq_{kind}_create")
+            return cls(kind, desc, h)
+        probe = cls._make(kind, desc)
+        names = probe.param_names()
+        if len(params) != len(names):
+            raise MvqError(f"Stack.bind: {len(params)} tensors for {len(names)} parameters")
+        ts = [_dev(p.detach(), n) for p, n in zip(params, names)]
+        for t, (n, shp) in zip(ts, probe.param_info()):
+            if t.numel() != shp[0] * shp[1] * shp[2]:
+                raise MvqError(f"Stack.bind: {n} has {t.numel()} elements, expected shape {shp}")
+        blob = torch.empty(int(L.mvq_stack_weights_bytes(probe.handle)), device=ts[0].device, dtype=torch.uint8)
+        arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        check(create(ctypes.byref(h), ctypes.byref(desc), arr, blob.data_ptr(), blob.numel(), _stream()), f"mvq_{kind}_create")
+        return cls(kind, desc, h, blob)
+
+    @classmethod
+    def encoder(cls, d_model, strides, d_latent, params=None):
+        d = _lib.EncoderDesc()
+        d.d_model, d.n_strides, d.d_latent = int(d_model), len(strides), int(d_latent)
+        for i, s in enumerate(strides):
+            d.strides[i] = int(s)
+        return cls._make("encoder", d, params)
+
+    @classmethod
+    def decoder(cls, input_channel, channels, rates, d_out=1, output_padding=False, params=None):
+        d = _lib.DecoderDesc()
+        d.input_channel, d.channels, d.n_rates, d.d_out, d.output_padding = int(input_channel), int(channels), len(rates), int(d_out), int(bool(output_padding))
+        for i, s in enumerate(rates):
+            d.rates[i] = int(s)
+        return cls._make("decoder", d, params)
+
+    def bind(self, params):
+        return Stack._make(self.kind, self.desc, list(params))
+
+    def __del__(self):
+        try:
+            Stack._BY_ID.pop(getattr(self, "id", None), None)
+            if self.handle:
+                _lib.lib().mvq_stack_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def param_info(self):
+        import ctypes
+        L = _lib.lib()
+        out = []
+        for i in range(L.mvq_stack_param_count(self.handle)):
+            buf = ctypes.create_string_buffer(128)
+            dims = (ctypes.c_int * 3)()
+            check(L.mvq_stack_param_info(self.handle, i, buf, 128, dims), "mvq_stack_param_info")
+            out.append((buf.value.decode(), tuple(dims)))
+        return out
+
+    def param_names(self):
+        return [n for n, _ in self.param_info()]
+
+    def set_plan(self, vpack_min_batch=0, pack_min_batch=0):
+        check(_lib.lib().mvq_stack_set_plan(self.handle, int(vpack_min_batch), int(pack_min_batch)), "mvq_stack_set_plan")
+
+    def out_len(self, t):
+        L = _lib.lib()
+        return int(L.mvq_encoder_out_len(self.handle, int(t)) if self.kind == "encoder" else L.mvq_decoder_out_len(self.handle, int(t)))
+
+    def _ws(self, x, B, t):
+        L = _lib.lib()
+        n = L.mvq_encoder_workspace_bytes(self.handle, B, t) if self.kind == "encoder" else L.mvq_decoder_workspace_bytes(self.handle, B, t)
+        return torch.empty(max(int(n), 256), device=x.device, dtype=torch.uint8)
+
+    def encoder_fwd(self, x):
+        """x[B, 1, T] -> z[B, d_latent, Tl]: mvq_encoder_fwd_f32."""
+        x = _dev(x, "x")
+        B, _, T = x.shape
+        z = torch.empty(B, self.desc.d_latent, max(self.out_len(T), 0), device=x.device, dtype=torch.float32)
+        if z.numel():
+            ws = self._ws(x, B, T)
+            check(_lib.lib().mvq_encoder_fwd_f32(self.handle, x.data_ptr(), z.data_ptr(), ws.data_ptr(), ws.numel(), B, T, _stream()), "mvq_encoder_fwd_f32")
+        return z
+
+    def decoder_fwd(self, z):
+        """z[B, C, t] -> y[B, d_out, Tout] (tanh applied): mvq_decoder_fwd_f32."""
+        z = _dev(z, "z")
+        B, _, t = z.shape
+        y = torch.empty(B, self.desc.d_out, max(self.out_len(t), 0), device=z.device, dtype=torch.float32)
+        if y.numel():
+            ws = self._ws(z, B, t)
+            check(_lib.lib().mvq_decoder_fwd_f32(self.handle, z.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), B, t, _stream()), "mvq_decoder_fwd_f32")
+        return y
+
+    def decoder_fwd_saving(self, z):
+        """-> (y, saved): the training forward; `saved` (one uint8 tensor) goes to decoder_bwd_input."""
+        z = _dev(z, "z")
+        B, _, t = z.shape
+        L = _lib.lib()
+        y = torch.empty(B, self.desc.d_out, self.out_len(t), device=z.device, dtype=torch.float32)
+        saved = torch.empty(int(L.mvq_decoder_saved_bytes(self.handle, B, t)), device=z.device, dtype=torch.uint8)
+        ws = self._ws(z, B, t)
+        check(L.mvq_decoder_fwd_saving_f32(self.handle, z.data_ptr(), y.data_ptr(), saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(), B, t,
+                                           _stream()), "mvq_decoder_fwd_saving_f32")
+        return y, saved
+
+    def decoder_bwd_input(self, saved, gy, batch, t):
+        """dL/dz [batch, C, t] from dL/dy and the saved forward: mvq_decoder_bwd_input_f32."""
+        gy = _dev(gy, "gy")
+        gz = torch.empty(batch, self.desc.input_channel, t, device=gy.device, dtype=torch.float32)
+        ws = self._ws(gy, batch, t)
+        check(_lib.lib().mvq_decoder_bwd_input_f32(self.handle, saved.data_ptr(), saved.numel(), gy.data_ptr(), gz.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                   batch, t, _stream()), "mvq_decoder_bwd_input_f32")
+        return gz

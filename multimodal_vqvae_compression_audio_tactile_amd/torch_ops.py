@@ -11,6 +11,9 @@ shape-only fake implementation; the real one is the HIP kernel behind ``ops.py``
   vq_rvq_search_f32           mvq_rvq_ema_forward_f32    ResidualVQEMA.forward, Training/compare_dacvsproposal_5.py:253-265
   vq_cosine_rvq_f32           mvq_dac_rvq_f32            upstream dac ResidualVectorQuantize.forward, ...5.py:295
   ema_update_f32              mvq_rvq_ema_step_f32       ResidualVQEMA.ema_step, ...5.py:266-277 (mutates `books`)
+  encoder_fwd                 mvq_encoder_fwd_f32        A_ENC(a) / T_ENC(t), ...5.py:294,296 (whole stack: `stack` = ops.Stack(...).id)
+  decoder_fwd                 mvq_decoder_fwd_f32        T_DEC(z), ...5.py:322
+  decoder_bwd_input           mvq_decoder_fwd_saving_f32 + mvq_decoder_bwd_input_f32: dL/dz of T_DEC, ...5.py:393
 
 Weights are the PACKED images of ``ops.pack_conv1d`` / ``ops.pack_conv_transpose1d`` (made once per weight load).  Import this module
 to register (``import multimodal_vqvae_compression_audio_tactile_amd.torch_ops``); the package does not import it by itself.
@@ -96,5 +99,40 @@ def _(books, z_tokens, decay):
     return None
 
 
-REGISTERED = ("conv1d_snake_f32", "conv_transpose1d_snake_f32", "residual_unit_f32", "vq_rvq_search_f32", "vq_cosine_rvq_f32",
+@torch.library.custom_op(f"{NS}::encoder_fwd", mutates_args=())
+def encoder_fwd(x: Tensor, stack: int) -> Tensor:
+    return ops.Stack.by_id(stack).encoder_fwd(x)
+
+
+@encoder_fwd.register_fake
+def _(x, stack):
+    st = ops.Stack.by_id(stack)
+    return x.new_empty(x.shape[0], st.desc.d_latent, max(st.out_len(x.shape[-1]), 0))
+
+
+@torch.library.custom_op(f"{NS}::decoder_fwd", mutates_args=())
+def decoder_fwd(z: Tensor, stack: int) -> Tensor:
+    return ops.Stack.by_id(stack).decoder_fwd(z)
+
+
+@decoder_fwd.register_fake
+def _(z, stack):
+    st = ops.Stack.by_id(stack)
+    return z.new_empty(z.shape[0], st.desc.d_out, max(st.out_len(z.shape[-1]), 0))
+
+
+@torch.library.custom_op(f"{NS}::decoder_bwd_input", mutates_args=())
+def decoder_bwd_input(z: Tensor, gy: Tensor, stack: int) -> Tensor:
+    """dL/dz of y = T_DEC(z) for a given dL/dy: saving forward + input-gradient backward (weights frozen)."""
+    st = ops.Stack.by_id(stack)
+    _, saved = st.decoder_fwd_saving(z)
+    return st.decoder_bwd_input(saved, gy, z.shape[0], z.shape[-1])
+
+
+@decoder_bwd_input.register_fake
+def _(z, gy, stack):
+    return torch.empty_like(z)
+
+
+REGISTERED = ("encoder_fwd", "decoder_fwd", "decoder_bwd_input", "conv1d_snake_f32", "conv_transpose1d_snake_f32", "residual_unit_f32", "vq_rvq_search_f32", "vq_cosine_rvq_f32",
               "ema_update_f32")

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(so, n)]
     assert not missing, missing
     assert sorted(_lib.EXPORTS) == names, set(names) ^ set(_lib.EXPORTS)     # the ctypes table binds all of them
-    assert _lib.lib().mvq_abi_version() == 2
+    assert _lib.lib().mvq_abi_version() == 3
     assert _lib.lib().mvq_build_flags() == 0 == _lib.build_flags()          # product build, no A/B knob in the environment
 
 
@@ -43,7 +43,10 @@ def test_host_only_entry_points():
         v = [int(x) for x in re.findall(r"-?\d+", name.split("<")[1])]
         return tuple(v[:3] + v[4:])
     assert tile(ops.conv_kernel_name(768, 768, 7, 1, 9, tin=600)) == (7, 1, 9, 2, 2, 2, 2, 0)             # 128 x 128 tile
-    assert tile(ops.conv_kernel_name(768, 768, 7, 1, 9, tin=600, batch=1)) == (7, 1, 9, 1, 1, 2, 2, 0)    # latency regime: 64 x 64
+    assert ops.conv_kernel_name(768, 768, 7, 1, 9, tin=600, batch=1) == "conv1d_lat_kernel<7, 1, 9, 16>"   # latency regime: one wave per 16 x 16 tile (16x16x4 MFMA)
+    assert tile(ops.conv_kernel_name(768, 768, 7, 1, 9, tin=1200, batch=1)) == (7, 1, 9, 1, 1, 2, 2, 0)   # ... too many tiles for that: 64 x 64
+    assert ops.conv_kernel_name(1024, 1024, 1, tin=16, batch=6) == "conv1d_lat_kernel<1, 1, 1, 64>"        # a predictor GEMM over one AR chunk of six segments
+    assert tile(ops.conv_kernel_name(768, 768, 1, tin=600, batch=1)) == (1, 1, 1, 1, 1, 2, 2, 0)          # many tiles, short chain: stays LDS-tiled
     assert tile(ops.conv_kernel_name(1024, 1536, 7, tin=75, batch=64)) == (7, 1, 1, 1, 3, 4, 1, 0)        # latent rate: 128 x 96
     assert tile(ops.conv_kernel_name(1536, 768, 16, 8, 1, True, tin=75)) == (2, 1, 1, 1, 3, 4, 1, 8)      # polyphase convT, 8 phases
     assert ops.conv_kernel_name(1, 64, 7) == "conv1d_cin1_kernel<7>" and ops.conv_kernel_name(40, 24, 5, 2, 2) == "conv1d_direct_kernel"
@@ -265,6 +268,37 @@ def test_torch_ops_are_registered_with_shape_only_fakes():
     assert zq.shape == (2, 1024, 75) and codes.shape == (2, 8, 75) and codes.dtype == torch.int64 and lat.shape == (2, 64, 75)
     with pytest.raises(Exception):                       # the real implementations have no CPU path
         o.conv1d_snake_f32(torch.zeros(1, 16, 8), torch.zeros(4), None, None, None, None, 16, 1, 1, 0, 1)
+    # whole stacks: a description-only handle (no weights, no device) answers the shape questions of the fakes
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    enc = ops.Stack.encoder(64, (2, 4, 5, 8), 1024); dec = ops.Stack.decoder(1024, 1536, (8, 5, 4, 2))
+    assert o.encoder_fwd(m(3, 1, 24000), enc.id).shape == (3, 1024, 75)
+    assert o.decoder_fwd(m(3, 1024, 75), dec.id).shape == (3, 1, 23992)
+    assert o.decoder_bwd_input(m(2, 1024, 75), m(2, 1, 23992), dec.id).shape == (2, 1024, 75)
+
+
+def test_stack_handles_name_the_upstream_state_dict():
+    """include/mvq.h "whole stacks": the parameter list a stack expects IS the upstream state-dict of the module it replaces (names,
+    order of the module tree, shapes), so a checkpoint binds by name; lengths, workspace and blob queries need no device."""
+    from multimodal_vqvae_compression_audio_tactile_amd import _lib, dac, ops
+    for mod, st in ((dac.Encoder(), ops.Stack.encoder(64, dac.ENC_RATES, 1024)), (dac.Decoder(), ops.Stack.decoder(1024, 1536, dac.DEC_RATES))):
+        sd = mod.state_dict()
+        info = st.param_info()
+        assert [n for n, _ in info] == list(sd.keys())
+        for n, shp in info:
+            assert int(torch.tensor(shp).prod()) == sd[n].numel(), n
+    enc, dec = ops.Stack.encoder(64, dac.ENC_RATES, 1024), ops.Stack.decoder(1024, 1536, dac.DEC_RATES)
+    assert [enc.out_len(t) for t in (24000, 320 * 18, 100, 0)] == [75, 18, 0, 0]                 # a clip shorter than a token: empty
+    assert [dec.out_len(t) for t in (75, 18, 1, 0)] == [23992, 5752, 312, 0]
+    assert ops.Stack.decoder(1024, 1536, dac.DEC_RATES, output_padding=True).out_len(75) == 24000
+    L = _lib.lib()
+    assert L.mvq_encoder_workspace_bytes(enc.handle, 1, 24000) < 64 << 20
+    assert 4 << 30 < L.mvq_encoder_workspace_bytes(enc.handle, 256, 24000) < 8 << 30          # a few tensors of the widest stage, not one per layer
+    assert L.mvq_decoder_saved_bytes(dec.handle, 256, 75) > 40 << 30                           # the training forward keeps every Snake input
+    assert L.mvq_stack_weights_bytes(dec.handle) > 2 * 4 * 52_000_000                          # forward + input-gradient images
+    with pytest.raises(_lib.MvqError):                                                         # no weights bound: the forward refuses
+        _lib.check(L.mvq_encoder_fwd_f32(enc.handle, 1, 1, 1, 1024, 1, 24000, None), "mvq_encoder_fwd_f32")
+    with pytest.raises(_lib.MvqError):
+        ops.Stack.encoder(64, (), 1024)
 
 
 def test_opt_in_mode_entry_points_validate_their_arguments():
