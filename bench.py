@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 latency section (reference protocol)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline = null)")
+    ap.add_argument("--allow-overrides", action="store_true", help="run although launch-plan A/B switches are set in the environment "
+                    "(MVQ_PY_PLAN, MVQ_RU_PRESNAKED, MVQ_TWO_STREAM_MAX_BATCH, ...): the line then lists them in `plan_overrides`")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the batch sweep (B = 1, 6, 64) behind the headline")
     ap.add_argument("--arith", choices=["f32", "bf16x6", "f16x3"], default="f32",
                     help="f32 (default, the headline): the exact fp32 fma chains of the arithmetic contract.  bf16x6: the OPT-IN, "
                          "NON-PARITY mode -- the wide units' 7-tap convs as six bf16 piece products per fp32 product (fp32-accurate, "
@@ -189,7 +192,7 @@ def fatal(rank, msg, code=3):
     os._exit(code)
 
 
-def pmc_traffic_table():
+def pmc_traffic_table(want=None):
     """profiles/pmc_traffic.json (HBM bytes per launch per kernel, from two rocprofv3 --pmc passes of this same command,
     tools/pmc_traffic.py) + where it came from: the commit it was profiled at and whether csrc/ still has the same content."""
     f = ROOT / "profiles" / "pmc_traffic.json"
@@ -202,7 +205,12 @@ def pmc_traffic_table():
     meta = tab.pop("_meta", {}) if isinstance(tab, dict) else {}
     from tools.pmc_traffic import csrc_digest
     now = csrc_digest(ROOT)
-    src = {"file": "profiles/pmc_traffic.json", "profiled_at_commit": meta.get("commit"),
+    # the per-launch bytes describe launches of ONE command (kernel names repeat across workloads with other shapes): tables without
+    # the stamp are the default command's (round <= 4: joint, 256 segments, f32)
+    ran = (meta.get("workload", "joint"), int(meta.get("batch", 256)), meta.get("arith", "f32"))
+    if want is not None and ran != want:
+        return {}, None
+    src = {"file": "profiles/pmc_traffic.json", "profiled_at_commit": meta.get("commit"), "profiled_command": {"workload": ran[0], "batch": ran[1], "arith": ran[2]},
            "csrc_sha16_profiled": meta.get("csrc_sha16"), "csrc_sha16_now": now,
            "kernels_unchanged_since_profile": bool(meta.get("csrc_sha16")) and meta.get("csrc_sha16") == now}
     return tab, src
@@ -228,6 +236,36 @@ def vq_lds_table():
             "source": {"file": "profiles/pmc_vq_lds.json", "profiled_at_commit": meta.get("commit"),
                        "csrc_sha16_profiled": meta.get("csrc_sha16"), "csrc_sha16_now": now,
                        "kernels_unchanged_since_profile": bool(meta.get("csrc_sha16")) and meta.get("csrc_sha16") == now}}
+
+
+def batch_sweep(net, synth, dev, tact, gflop_per_segment, headline_batch, y_headline):
+    """The reference's own operating points next to the headline (B in {1, 6, 64, 256}; the eval
+    loader and the training loop run batches of 6, Evaluation/compare_dacvsproposal_5_eval.py:487-489, Training/...5.py:62): the
+    same forward_eval on the first B segments of the headline batch, 3 warm-ups + timed repeats with the inputs resident, ms per
+    step, segments/s and the algorithmic fraction of the fp32 MFMA peak -- each under the headline's rule: rows of the B-segment
+    output must equal the same segments' rows of the headline output bit for bit (batch independence), else the run fails."""
+    out = {}
+    a_all = synth.audio_segments(max(64, 1), seed=7).to(dev); t_all = synth.tactile_segments(max(64, 1), seed=7).to(dev)
+    fwd = (lambda a, t: net.forward_eval_tactile_only(t, books_use=None)) if tact else (lambda a, t: net.forward_eval(a, t, books_use=None))
+    for B in (1, 6, 64):
+        a, t = a_all[:B].contiguous(), t_all[:B].contiguous()
+        for _ in range(3):
+            y = fwd(a, t)
+        torch.cuda.synchronize()
+        reps = {1: 50, 6: 30, 64: 8}[B]
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y = fwd(a, t)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+        n = min(B, headline_batch, y_headline.shape[0])
+        same = bool(torch.equal(y[:n], y_headline[:n])) if y.shape[1:] == y_headline.shape[1:] else False
+        tf = B * gflop_per_segment / ms                          # GFLOP / ms = TFLOP/s
+        out[f"B{B}"] = {"ms_per_step": ms, "segments_per_s": 1e3 * B / ms, "path_tflops": tf, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS,
+                        "rows_bit_equal_to_headline_batch": same, "repeats": reps}
+    out["note"] = ("same synthetic segments as rows 0..B-1 of the headline batch (seed 7, rank 0); eager calls, inputs resident, "
+                   "device synchronised around the timed repeats")
+    return out
 
 
 def latency_b1(mvq, synth, dev, books, embed, sd):
@@ -307,6 +345,11 @@ def main():
 
     import multimodal_vqvae_compression_audio_tactile_amd as mvq
     from multimodal_vqvae_compression_audio_tactile_amd import ops, synth
+    overrides = mvq.plan_overrides()
+    if overrides and not args.allow_overrides:
+        print(f"bench.py: launch-plan A/B switches in the environment ({', '.join(overrides)}): not the product's plan; "
+              "pass --allow-overrides to measure it anyway (the line lists them)", file=sys.stderr)
+        sys.exit(2)
     ops.set_arith(args.arith)                                    # "f32" unless the opt-in, non-parity mode was asked for
 
     sd = synth.proposed_model_state(7, rvq_books=args.books, rvq_embed=args.embed)
@@ -471,7 +514,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.arith, "data": "synthetic",
             "segments_per_s": seg_s, "output_finite": out_ok, "rccl_ranks": rccl_ranks,
             "parity_spot_check": (spot_ok if spot is not None else None), "parity_spot_check_detail": spot,
-            "build_flags": ops.build_flags(), "arith": args.arith, "arith_check": arith_check,
+            "build_flags": ops.build_flags(), "plan_overrides": overrides, "arith": args.arith, "arith_check": arith_check,
             "config": {"workload": ("joint audio+tactile ProposedEval.forward_eval (compare_dacvsproposal_5 config: "
                                     "2x DAC-24k encoder, 32x1024x8 audio RVQ, CrossPredictor AR x5 chunks, "
                                     f"RVQ {args.books}x{args.embed}x96, DAC-24k decoder)") if not tact else
@@ -512,7 +555,7 @@ def main():
             dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
             name, d = dom
             ach = d["flops"] / d["seconds"] * 1e-12
-            pmc_all, pmc_src = pmc_traffic_table()
+            pmc_all, pmc_src = pmc_traffic_table((args.workload, args.batch, args.arith))
             traffic = pmc_all.get(name, {}).get("hbm_bytes_per_launch")       # null when this kernel is not in the profile
             # a bf16x6 kernel (opt-in mode only) spends six bf16 MFMA products per algorithmic fp32 product: its ceiling is the dense
             # bf16 MFMA peak / 6, in the same algorithmic TFLOP/s the other kernels are quoted in
@@ -545,6 +588,11 @@ def main():
             vq = vq_lds_table()
             if vq:
                 line["vq"] = vq
+        if world == 1 and not train and not args.no_sweep and args.arith == "f32":
+            try:
+                line["batch_sweep"] = batch_sweep(net, synth, dev, tact, GFLOP_PER_SEGMENT[args.workload], B, y)
+            except Exception as ex:
+                line["batch_sweep"] = {"error": repr(ex)}
         if world == 1 and not train and not args.no_latency:
             try:
                 line["latency_b1"] = latency_b1(mvq, synth, dev, args.books, args.embed, sd)
@@ -558,6 +606,10 @@ def main():
             except Exception as ex:       # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "token-frames/s", "cores": torch.get_num_threads(),
                                         "kind": "port", "sample": f"failed: {ex!r}"}
+        sweep_ok = all(v.get("rows_bit_equal_to_headline_batch", True) for v in line.get("batch_sweep", {}).values() if isinstance(v, dict))
+        if not sweep_ok:
+            print("[bench] batch sweep: a small-batch output differs from the same segments of the headline batch", file=sys.stderr, flush=True)
+            spot_ok = False
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist:

@@ -18,6 +18,7 @@ from . import ops, optim, synth, train  # noqa: F401
 from .resample import Resample, resample_to  # noqa: F401
 from .losses import MelCosineLoss, MultiResSTFTLoss, TrainingLoss, safe_l1, stsim_batch  # noqa: F401
 from ._lib import MvqError, build, lib  # noqa: F401
+from .dac import plan_overrides  # noqa: F401
 from .dac import DAC, Decoder, Encoder, ResidualVectorQuantize, VectorQuantize, Snake1d, WNConv1d, WNConvTranspose1d  # noqa: F401
 from .proposed import (AllPredAR, AllPredAR3, CrossPredictor, PosEnc1D, ProposedEval, ProposedWrapper, ResidualVQEMA, TokenNorm,  # noqa: F401
                        psnr_batch, psnr_global_peak_db, align_by_xcorr, crop_match, align_pair_24k,

@@ -36,12 +36,13 @@ DEC_RATES = (8, 5, 4, 2)
 # whole-stack C entry points (mvq_encoder_fwd_f32 / mvq_decoder_fwd_f32 / mvq_decoder_bwd_input_f32), whose plan is the library's.
 PLAN_ENV = ("MVQ_RU_PRESNAKED", "MVQ_VPACKED_LATENTS", "MVQ_PACKED_MIN_BATCH", "MVQ_PACKED_LATENTS", "MVQ_PY_PLAN")
 PLAN_OVERRIDES = {k: os.environ[k] for k in PLAN_ENV if k in os.environ}
+HOST_ENV_SEEN = {k: os.environ[k] for k in ("MVQ_TWO_STREAM_MAX_BATCH",) if k in os.environ}      # proposed.py: stream plan of the branches
 USE_STACKS = not PLAN_OVERRIDES            # tests flip this to compare the two plans
 
 
 def plan_overrides():
     """Names of the launch-plan / arithmetic A/B switches seen in the environment at import (empty in a product run)."""
-    return sorted(PLAN_OVERRIDES) + sorted(ops.ARITH_ENV_SEEN)
+    return sorted(PLAN_OVERRIDES) + sorted(HOST_ENV_SEEN) + sorted(ops.ARITH_ENV_SEEN)
 
 
 class _Packed:
@@ -62,6 +63,23 @@ class _Packed:
             self.value = make()
             self._key = key
         return self.value
+
+
+def _stack_of(mod, describe):
+    """Cached mvq_stack of an Encoder / Decoder.  The parameter list (upstream state-dict order) is resolved once; a call only
+    compares a cheap stamp -- version counters, first storage address, device -- so that load_state_dict / .to() / an in-place
+    update rebuild the handle (edits through ``param.data`` bypass the counters: call ``mod._stack_state = None`` after one)."""
+    st = getattr(mod, "_stack_state", None)
+    if st is None or st.get("probe") is None:              # first use, or a deep copy / unpickled module (handles are not copied)
+        probe = describe()
+        named = dict(mod.named_parameters())
+        st = mod._stack_state = {"probe": probe, "params": [named[n] for n in probe.param_names()], "stamp": None, "stack": None}
+    ps = st["params"]
+    stamp = (sum(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr(), ps[0].device)
+    if stamp != st["stamp"]:
+        st["stack"] = st["probe"].bind(ps)
+        st["stamp"] = stamp
+    return st["stack"]
 
 
 class Snake1d(nn.Module):
@@ -298,14 +316,10 @@ class Encoder(nn.Module):
         layers += [Snake1d(d_model), WNConv1d(d_model, d_latent, 3, padding=1)]
         self.block = nn.Sequential(*layers)
         self.enc_dim = d_model
-        self._stack_cache = _Packed()
 
     def stack(self):
         """The mvq_stack of this encoder (include/mvq.h): weights folded and packed once per parameter version."""
-        named = dict(self.named_parameters())
-        probe = ops.Stack.encoder(*self._desc)
-        params = [named[n] for n in probe.param_names()]
-        return self._stack_cache.get(params, lambda: probe.bind(params))
+        return _stack_of(self, lambda: ops.Stack.encoder(*self._desc))
 
     @torch.no_grad()
     def forward(self, x):
@@ -412,14 +426,10 @@ class Decoder(nn.Module):
         layers += [Snake1d(out), WNConv1d(out, d_out, 7, padding=3), nn.Tanh()]
         self.model = nn.Sequential(*layers)
         self._desc = (int(input_channel), int(channels), tuple(int(r) for r in rates), int(d_out), bool(output_padding))
-        self._stack_cache = _Packed()
 
     def stack(self):
         """The mvq_stack of this decoder (forward + input-gradient images), made once per parameter version."""
-        named = dict(self.named_parameters())
-        probe = ops.Stack.decoder(*self._desc)
-        params = [named[n] for n in probe.param_names()]
-        return self._stack_cache.get(params, lambda: probe.bind(params))
+        return _stack_of(self, lambda: ops.Stack.decoder(*self._desc))
 
     def _stacked(self, z) -> bool:
         return USE_STACKS and ops.get_arith() == "f32" and z.is_cuda and z.shape[0] > 0 and z.shape[-1] > 0

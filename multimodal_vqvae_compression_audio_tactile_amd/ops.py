@@ -844,6 +844,12 @@ class Stack:
         self.id = id(self)
         Stack._BY_ID[self.id] = weakref.ref(self)
 
+    def __deepcopy__(self, memo):            # a handle is not copied with its module: the copy rebuilds its own on first use
+        return None
+
+    def __reduce__(self):                    # ... nor pickled (torch.save(module)): it pickles as None
+        return (type(None), ())
+
     @classmethod
     def by_id(cls, i):
         ref = cls._BY_ID.get(int(i))

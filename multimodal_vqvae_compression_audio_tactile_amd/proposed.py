@@ -27,6 +27,7 @@ import torch.nn as nn
 
 from . import ops, train
 from ._lib import MvqError
+from . import dac as _dac
 from .dac import _Packed
 
 CODE_DIM = 96        # Training/compare_dacvsproposal_5.py:68
@@ -268,7 +269,7 @@ class _ProposedBase(nn.Module):
     # box), but concurrent kernels stretch each other's durations, so the per-kernel HIP-event / rocprofv3 figures the bench
     # reports (roofline of the dominant kernel) would no longer describe a kernel running alone.  The default therefore keeps
     # one stream at throughput batch sizes; MVQ_TWO_STREAM_MAX_BATCH raises the cap.
-    TWO_STREAM_MAX_BATCH = int(os.environ.get("MVQ_TWO_STREAM_MAX_BATCH", "64"))
+    TWO_STREAM_MAX_BATCH = int(_dac.HOST_ENV_SEEN.get("MVQ_TWO_STREAM_MAX_BATCH", "64"))      # read once at import, reported by plan_overrides()
 
     def _encode_branches(self, a_1T, t_1T):
         """qa = A_QUANT(A_ENC(a)) and zt = T_ENC(t) are independent.  In the latency regime (few segments: every

@@ -276,6 +276,20 @@ def test_torch_ops_are_registered_with_shape_only_fakes():
     assert o.decoder_bwd_input(m(2, 1024, 75), m(2, 1, 23992), dec.id).shape == (2, 1024, 75)
 
 
+def test_operators_trace_through_torch_compile():
+    """The operator face is traceable: torch.compile(fullgraph=True) builds ONE graph through a torch.ops.mi355x_vqvae call (dynamo
+    runs the shape-only fake; backend "eager" then executes it on meta tensors) -- no graph break, no fallback to Python."""
+    import multimodal_vqvae_compression_audio_tactile_amd.torch_ops  # noqa: F401
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    m = lambda *s: torch.empty(*s, device="meta")
+    o = torch.ops.mi355x_vqvae
+    f = torch.compile(lambda x, wp, b: o.conv1d_snake_f32(x, wp, b, None, None, None, 128, 4, 2, 1, 1) * 2.0, fullgraph=True, backend="eager")
+    assert f(m(3, 64, 100), m(10), m(128)).shape == (3, 128, 50)
+    enc = ops.Stack.encoder(64, (2, 4, 5, 8), 1024); dec = ops.Stack.decoder(1024, 1536, (8, 5, 4, 2))
+    g = torch.compile(lambda x: o.decoder_fwd(o.encoder_fwd(x, enc.id), dec.id), fullgraph=True, backend="eager")
+    assert g(m(2, 1, 24000)).shape == (2, 1, 23992)
+
+
 def test_stack_handles_name_the_upstream_state_dict():
     """include/mvq.h "whole stacks": the parameter list a stack expects IS the upstream state-dict of the module it replaces (names,
     order of the module tree, shapes), so a checkpoint binds by name; lengths, workspace and blob queries need no device."""

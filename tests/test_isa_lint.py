@@ -103,3 +103,4 @@ def test_shipped_library_passes_the_isa_lint():
     assert not bad, "\n".join(bad[:20])
     # not vacuous: the LDS-DMA kernels with hand-placed operand reads are in the binary and were all inspected
     assert summary["kernels"] >= 100 and summary["asm_read_kernels"] >= 40, summary
+    assert summary.get("metadata_checked", 0) >= summary["kernels"] - 5, summary          # R3 looked at the metadata of every kernel

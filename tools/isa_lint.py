@@ -11,8 +11,9 @@ Checks (every kernel of the library unless noted):
       N youngest LDS operations are done (an outstanding scalar load only makes the wait longer).  The in-flight queue is
       propagated over the kernel's control-flow graph (every distinct queue that can reach a basic block is simulated), so loops
       and the compiler's block placement are handled exactly; compiler-issued reads are judged by the same rule.
-  R3  the MFMA conv kernels (every conv1d_mfma_kernel / residual_unit_kernel instantiation, LDS-DMA or register-staged) use no
-      scratch: zero `scratch_` instructions, and a zero private segment / no VGPR spills in the metadata of the LDS-DMA ones.
+  R3  NO kernel of the library uses scratch (round 5: every kernel, not only the MFMA conv kernels): zero `scratch_` instructions,
+      and in the code-object metadata a zero private segment and no VGPR spills.  A register array indexed at run time, or a
+      register budget the allocator cannot meet, would otherwise turn into private-memory traffic silently.
   R4  every `global_load_lds_dwordx4` sits inside a burst of the exact shape
           s_mov_b32 sK, m0 / s_mov_b32 m0, sD / { s_nop 0 / global_load_lds_dwordx4 ... / [s_add_u32 m0, m0, imm] }+ / s_mov_b32 m0, sK
       and no other instruction of such a kernel writes M0.
@@ -326,29 +327,21 @@ def run(so: Path, kernel_filter: str | None = None, want_stats: bool = False, du
             summary["dma_kernels"] += has_dma
             summary["asm_read_kernels"] += has_asm
             violations += lint_function(name, insns)
-            if has_dma or "conv1d_mfma_kernel" in name or "residual_unit_kernel" in name:
-                n_scr = sum(1 for _, op, _ in insns if op.startswith("scratch_"))
-                if n_scr:
-                    violations.append(f"{name}: {n_scr} scratch_ instructions in an MFMA conv kernel (R3)")
+            n_scr = sum(1 for _, op, _ in insns if op.startswith("scratch_"))
+            if n_scr:
+                violations.append(f"{name}: {n_scr} scratch_ instructions (R3)")
             if want_stats:
                 summary["stats"][name] = stats(insns)
-        # R3 (metadata): private segment of the DMA kernels
-        dma_syms = set()
-        for name, insns in funcs.items():
-            if any(op.startswith("global_load_lds") for _, op, _ in insns):
-                dma_syms.add(name)
-        if dma_syms:
-            # metadata names are mangled; demangle them to match
-            names = list(meta)
-            if names:
-                dem = demangle(names)
-                for mname, dname in zip(names, dem):
-                    base = dname.split("(")[0]
-                    hit = [n for n in dma_syms if n.split("(")[0] == base]
-                    if hit and (not kernel_filter or kernel_filter in dname):
-                        md = meta[mname]
-                        if md["private"] or md["vgpr_spill"]:            # (SGPR spills go to VGPR lanes, not to memory)
-                            violations.append(f"{dname}: private segment {md['private']} B, spills v{md['vgpr_spill']} s{md['sgpr_spill']} in an LDS-DMA kernel (R3)")
+        # R3 (metadata): private segment / VGPR spills of EVERY kernel (SGPR spills go to VGPR lanes, not to memory)
+        names = list(meta)
+        if names:
+            for mname, dname in zip(names, demangle(names)):
+                if kernel_filter and kernel_filter not in dname:
+                    continue
+                md = meta[mname]
+                summary["metadata_checked"] = summary.get("metadata_checked", 0) + 1
+                if md["private"] or md["vgpr_spill"]:
+                    violations.append(f"{dname}: private segment {md['private']} B, spills v{md['vgpr_spill']} s{md['sgpr_spill']} (R3)")
     return violations, summary
 
 

@@ -37,12 +37,19 @@ def load(d, counter):
     return tot, cnt
 
 
+def _flag(cmd, name, default):
+    return cmd[cmd.index(name) + 1] if name in cmd and cmd.index(name) + 1 < len(cmd) else default
+
+
 def main(argv):
     fetch, nf = load(argv[1], "FETCH_SIZE")
     write, nw = load(argv[2], "WRITE_SIZE")
     root = Path(__file__).resolve().parent.parent
     out = {"_meta": {"commit": argv[4] if len(argv) > 4 else None, "csrc_sha16": csrc_digest(root),
                      "command": " ".join(argv[5:]) or None,
+                     # what the per-launch bytes describe: bench.py only quotes them for a run of the SAME workload / batch / arithmetic
+                     "workload": _flag(argv[5:], "--workload", "joint"), "batch": int(_flag(argv[5:], "--batch", "256")),
+                     "arith": _flag(argv[5:], "--arith", "f32"),
                      "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 wide coalesced reads); WRITE_SIZE as is"}}
     for k in fetch:
         n = nf[k]
