@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "det_math.hpp"
 #include "kernels_small.hpp"
 
@@ -476,21 +477,27 @@ __global__ __launch_bounds__(256) void rvq_ema_forward_token_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// Latency form, round 5: ONE BLOCK PER TOKEN, ONE THREAD PER CODE (K <= 512), the code row held in REGISTERS.
+// Latency form, round 5: ONE BLOCK PER TOKEN, ONE THREAD PER CODE (K <= 512), code rows through LDS in two halves.
 // profiles/r05_kernel_stats_B1_encode_before.csv: the form above costs 67 us per 16-token chunk -- 8.4 us per book, of which the
-// 96-step chains are ~0.4: the rest is each thread walking two 384-byte rows with at most four loads in flight, then a dependent
-// gather of the winner's row.  Here a thread fetches its whole row (DV 16-byte loads, all in flight) one BOOK AHEAD -- the rows do
-// not depend on the residual, only the scores do -- so a book costs its chains, one arg-max and the update; the winner publishes
-// the row it already holds (no gather).  Same chains as every other form: dot = sum_d r_d e_d and hs = sum_d e_d^2, d ascending
-// from +0; score = dot - 0.5 hs; strict '>' over ascending codes, lowest index on ties.
+// 96-step chains are ~0.4.  The rest is the access pattern: a thread walking its own 384-byte row makes every wave-load touch 64
+// different cache lines (~64 cycles of the CU's address pipe per instruction, 24 instructions x 8 waves per book), whether the
+// loads are issued one by one or all at once (the first round-5 cut held the rows in registers: 58 us).  Here the block fetches
+// the book COOPERATIVELY -- consecutive lanes take consecutive 16-byte pieces of a row, a wave-load covers five rows in ten
+// lines -- half a row (48 dimensions, 104 KB of LDS at pitch 52: conflict-free ds_read_b128 per code) at a time, the second half
+// and the next book's first half in flight while the chains of the current half run; a thread keeps the row it scored in
+// registers, so the winner publishes it without a gather.  Same chains as every other form: dot = sum_d r_d e_d and
+// hs = sum_d e_d^2, d ascending from +0; score = dot - 0.5 hs; strict '>' over ascending codes, lowest index on ties.
 // ------------------------------------------------------------------------------------------------
-template <int DV>                                       // 16-byte pieces per code row: D = 4 DV
-__global__ __launch_bounds__(512) void rvq_ema_forward_rows_kernel(
+template <int DV>                                       // 16-byte pieces per code row: D = 4 DV, fetched in two halves of DV / 2
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))     // one block per CU (104 KB of LDS): 256 VGPRs per lane
+void rvq_ema_forward_rows_kernel(
     const float* __restrict__ z, const float* __restrict__ books, float* __restrict__ q_out,
     int32_t* __restrict__ idx_out, int B, int T, int nb, int K, int update_residual)
 {
-    constexpr int D = 4 * DV;
+    constexpr int D = 4 * DV, HV = DV / 2, PITCH = 4 * HV + 4;
+    static_assert(DV % 2 == 0, "two equal halves");
     typedef float v4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float rows[];   // [K][PITCH]: one half of every code row
     __shared__ __attribute__((aligned(16))) float res[D], qs[D], qrow[D];
     __shared__ float ws[8];
     __shared__ int wi[8];
@@ -498,38 +505,81 @@ __global__ __launch_bounds__(512) void rvq_ema_forward_rows_kernel(
     const int n = blockIdx.x, N = B * T;
     const int b = n / T, t = n - b * T;
     const bool has = tid < K;
+    const int npieces = K * HV;
     if (tid < D) { res[tid] = z[((size_t)b * D + tid) * T + t]; qs[tid] = 0.0f; }
-    v4 e0[DV], e1[DV];
-    auto fetch = [&](v4 (&e)[DV], int bk) __attribute__((always_inline)) {
-        const float* row = books + ((size_t)bk * K + (has ? tid : 0)) * D;
+    v4 st[HV];                                                      // this thread's pieces of the half being fetched
+    unsigned goff[HV], loff[HV];                                    // their element offsets in a book / in the LDS image: the same for every half
+    unsigned livem = 0;
 #pragma unroll
-        for (int u = 0; u < DV; ++u) e[u] = *reinterpret_cast<const v4*>(row + 4 * u);
+    for (int u = 0; u < HV; ++u) {
+        const int e0 = tid + 512 * u;
+        const int ec = e0 < npieces ? e0 : npieces - 1;
+        const int r = ec / HV, v = ec - r * HV;
+        goff[u] = (unsigned)(r * D + 4 * v) * 4u;                   // bytes: uniform base + 32-bit lane offset, no 64-bit address per piece
+        loff[u] = (unsigned)(r * PITCH + 4 * v) * 4u;
+        livem |= e0 < npieces ? (1u << u) : 0u;
+    }
+    auto gfetch = [&](int bk, int h) __attribute__((always_inline)) {
+        // uniform base kept in scalar registers (readfirstlane: the loop's strength reduction would otherwise carry one 64-bit
+        // per-lane pointer per piece across the books -- 24 more registers, spilled to scratch)
+        const uintptr_t bu = reinterpret_cast<uintptr_t>(books + (size_t)bk * K * D + h * 4 * HV);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bu), hi = __builtin_amdgcn_readfirstlane((unsigned)(bu >> 32));
+        const char* base = reinterpret_cast<const char*>(((uintptr_t)hi << 32) | lo);
+#pragma unroll
+        for (int u = 0; u < HV; ++u) st[u] = *reinterpret_cast<const v4*>(base + goff[u]);
     };
-    auto book = [&](const v4 (&e)[DV], int bk) __attribute__((always_inline)) {
-        __syncthreads();                                           // res of this book is in place
+    auto lstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < HV; ++u)
+            if ((livem >> u) & 1u) *reinterpret_cast<v4*>(reinterpret_cast<char*>(rows) + loff[u]) = st[u];
+    };
+    v4 e0[HV];                                                      // first half of the row this thread scores: kept, the winner publishes it
+                                                                    // (the second half is still in LDS when the winner is known)
+    if (nb > 0) gfetch(0, 0);
+    for (int bk = 0; bk < nb; ++bk) {
+        const float* myrow = rows + (has ? tid : 0) * PITCH;
+        float dot = 0.0f, hs = 0.0f;
+        auto half = [&](auto H) __attribute__((always_inline)) {   // H = 0 / 1 as a compile-time constant: e[] stays in registers
+            constexpr int h = decltype(H)::value;
+            if (h == 1) __syncthreads();                           // every chain of the first half has read its row
+            lstore();
+            __syncthreads();                                       // the half (and, first time round, res) is in place
+            if (h == 0) gfetch(bk, 1);                             // in flight across the chains below
+            else if (bk + 1 < nb) gfetch(bk + 1, 0);
+            v4 ec[HV];
+#pragma unroll
+            for (int u = 0; u < HV; ++u) ec[u] = *reinterpret_cast<const v4*>(myrow + 4 * u);
+            if (h == 0) {
+#pragma unroll
+                for (int u = 0; u < HV; ++u) e0[u] = ec[u];
+            }
+#pragma unroll
+            for (int u = 0; u < HV; ++u) {
+                const v4 r = *reinterpret_cast<const v4*>(res + 4 * (h * HV + u));      // every lane the same address: a broadcast read
+                const v4 c = ec[u];
+                dot = dfma(r.x, c.x, dot); dot = dfma(r.y, c.y, dot); dot = dfma(r.z, c.z, dot); dot = dfma(r.w, c.w, dot);
+                hs = dfma(c.x, c.x, hs); hs = dfma(c.y, c.y, hs); hs = dfma(c.z, c.z, hs); hs = dfma(c.w, c.w, hs);
+            }
+        };
+        half(std::integral_constant<int, 0>{});
+        half(std::integral_constant<int, 1>{});
         float bs = -__builtin_inff(); int bi = 0x7fffffff;
         if (has) {
-            float dot = 0.0f, hs = 0.0f;
-#pragma unroll
-            for (int u = 0; u < DV; ++u) {
-                const v4 r = *reinterpret_cast<const v4*>(res + 4 * u);        // every lane the same address: one broadcast read
-                dot = dfma(r.x, e[u].x, dot); dot = dfma(r.y, e[u].y, dot); dot = dfma(r.z, e[u].z, dot); dot = dfma(r.w, e[u].w, dot);
-                hs = dfma(e[u].x, e[u].x, hs); hs = dfma(e[u].y, e[u].y, hs); hs = dfma(e[u].z, e[u].z, hs); hs = dfma(e[u].w, e[u].w, hs);
-            }
             const float sc = dot - 0.5f * hs;
             if (sc > bs) { bs = sc; bi = tid; }
         }
         wave_argmax(bs, bi);
         if (lane == 0) { ws[wave] = bs; wi[wave] = bi; }
-        __syncthreads();
+        __syncthreads();                                           // also: every chain of the second half has read its row
         float cs = ws[0]; int id = wi[0];
 #pragma unroll
         for (int w = 1; w < 8; ++w) amax_combine(cs, id, ws[w], wi[w]);
         if (id < 0 || id >= K) id = 0;                             // all-NaN scores: defined, in-range code
         if (tid == id) {
 #pragma unroll
-            for (int u = 0; u < DV; ++u) *reinterpret_cast<v4*>(qrow + 4 * u) = e[u];
+            for (int u = 0; u < HV; ++u) *reinterpret_cast<v4*>(qrow + 4 * u) = e0[u];
         }
+        if (tid >= 64 && tid < 64 + 4 * HV) qrow[4 * HV + tid - 64] = rows[id * PITCH + tid - 64];      // second half: the winner's row in LDS
         __syncthreads();
         if (tid < D) {
             const float q = qrow[tid];
@@ -538,15 +588,6 @@ __global__ __launch_bounds__(512) void rvq_ema_forward_rows_kernel(
             if (update_residual) res[tid] = r - q;
         }
         if (idx_out && tid == 0) idx_out[(size_t)bk * N + n] = id;
-    };
-    if (nb > 0) fetch(e0, 0);
-    for (int bk = 0; bk < nb; bk += 2) {
-        if (bk + 1 < nb) fetch(e1, bk + 1);                        // in flight across this book's chains and arg-max
-        book(e0, bk);
-        if (bk + 1 < nb) {
-            if (bk + 2 < nb) fetch(e0, bk + 2);
-            book(e1, bk + 1);
-        }
     }
     __syncthreads();
     if (q_out && tid < D) q_out[((size_t)b * D + tid) * T + t] = qs[tid];
@@ -564,7 +605,10 @@ hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_o
         return o;
     }();
     if (N <= 256 && D == 96 && K <= 512 && (reinterpret_cast<uintptr_t>(books) & 15) == 0 && !no_token_form) {   // CODE_DIM = 96 (Training/...5.py:68)
-        hipLaunchKernelGGL(rvq_ema_forward_rows_kernel<24>, dim3(N), dim3(512), 0, s, z, books, q_out, idx_out, B, T, nb, K, update_residual);
+        auto kern = rvq_ema_forward_rows_kernel<24>;
+        static BigLdsOptIn opt;                           // per device: 104 KB of dynamic LDS at K = 512
+        if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(N), dim3(512), (size_t)K * 52 * sizeof(float), s, z, books, q_out, idx_out, B, T, nb, K, update_residual);
         return hipGetLastError();
     }
     if (N <= 256 && D % 4 == 0 && D <= 128 && !no_token_form) {
@@ -963,6 +1007,11 @@ __global__ __launch_bounds__(256) void dac_rvq_lat_kernel(
         resr[j] = live ? z[((size_t)bb * C + c0 + j) * T + tt] : 0.0f;
         res_s[tk][c0 + j] = resr[j];
     }
+    // Loads are requested one phase ahead of their use and never more than ~56 at a time (the wave's vector-memory counter holds
+    // 63: with every row of a stage requested at its top -- 90 loads -- the in_proj phase had to wait for most of them, one L2
+    // latency per stage; gpurun_out/r05bsmall: 8.2 us per stage):
+    //   in_proj rows of stage s+1 and the out_proj rows behind the search | code rows (normalised) at the top | raw code rows
+    //   behind in_proj (only the winner's is used, after the arg-max).
     v4 iw[IV];                                                     // in_proj row piece of (stage, d_in, block g): CPT floats
     auto fetch_in = [&](int st) __attribute__((always_inline)) {
         const float* wr = in_w + ((size_t)st * Dc + d_in) * C + g * CPT;
@@ -971,22 +1020,15 @@ __global__ __launch_bounds__(256) void dac_rvq_lat_kernel(
     };
     fetch_in(0);
     for (int st = 0; st < nq; ++st) {
-        // rows this stage needs later, requested now: codes k = tl + 128 j (normalised + raw + squared norm), out_proj rows + bias
         v4 sw[KJ][2], rw[KJ][2], ow[CO][2];
         float cn2v[KJ], obv[CO];
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) {
+        for (int j = 0; j < KJ; ++j) {                             // codes k = tl + 128 j: normalised rows + squared norms
             const size_t k = (size_t)st * K + tl + 128 * j;
             sw[j][0] = *reinterpret_cast<const v4*>(cbn_pre + k * Dc); sw[j][1] = *reinterpret_cast<const v4*>(cbn_pre + k * Dc + 4);
-            rw[j][0] = *reinterpret_cast<const v4*>(cb + k * Dc); rw[j][1] = *reinterpret_cast<const v4*>(cb + k * Dc + 4);
             cn2v[j] = cn2_pre[k];
         }
-#pragma unroll
-        for (int j = 0; j < CO; ++j) {
-            const float* wr = out_w + ((size_t)st * C + c0 + j) * Dc;
-            ow[j][0] = *reinterpret_cast<const v4*>(wr); ow[j][1] = *reinterpret_cast<const v4*>(wr + 4);
-            obv[j] = out_b[(size_t)st * C + c0 + j];
-        }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                           // res_s holds this stage's residual
         {   // in_proj block partial: channels g*CPT .. +CPT-1 ascending, from +0
             const float* rr = &res_s[tk][g * CPT];
@@ -998,7 +1040,13 @@ __global__ __launch_bounds__(256) void dac_rvq_lat_kernel(
             }
             part[tk][g][d_in] = p;
         }
-        if (st + 1 < nq) fetch_in(st + 1);                         // next stage's in_proj rows: in flight across search and out_proj
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {                             // raw rows of the same codes (the straight-through value of the winner)
+            const size_t k = (size_t)st * K + tl + 128 * j;
+            rw[j][0] = *reinterpret_cast<const v4*>(cb + k * Dc); rw[j][1] = *reinterpret_cast<const v4*>(cb + k * Dc + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         if (tl < Dc) {                                             // the 16 block partials in block order, + bias
             float a = part[tk][0][tl];
@@ -1028,6 +1076,15 @@ __global__ __launch_bounds__(256) void dac_rvq_lat_kernel(
                 if (sc > bs) { bs = sc; bi = tl + 128 * j; }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CO; ++j) {                             // out_proj rows + bias of the owned channels; then the next stage's in_proj rows
+            const float* wr = out_w + ((size_t)st * C + c0 + j) * Dc;
+            ow[j][0] = *reinterpret_cast<const v4*>(wr); ow[j][1] = *reinterpret_cast<const v4*>(wr + 4);
+            obv[j] = out_b[(size_t)st * C + c0 + j];
+        }
+        if (st + 1 < nq) fetch_in(st + 1);
+        __builtin_amdgcn_sched_barrier(0);
         wave_argmax(bs, bi);                                       // a wave holds 64 threads of ONE token
         if (lane == 0) { red_s[tk][wv] = bs; red_i[tk][wv] = bi; }
         __syncthreads();
