@@ -497,10 +497,14 @@ void rvq_ema_forward_rows_kernel(
     constexpr int D = 4 * DV, HV = DV / 2, PITCH = 4 * HV + 4;
     static_assert(DV % 2 == 0, "two equal halves");
     typedef float v4 __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) float rows[];   // [K][PITCH]: one half of every code row
-    __shared__ __attribute__((aligned(16))) float res[D], qs[D], qrow[D];
-    __shared__ float ws[8];
-    __shared__ int wi[8];
+    // dynamic LDS only (the opt-in above 64 KB covers dynamic memory): res[D] | qs[D] | qrow[D] | ws[8] | wi[8] | rows[K][PITCH]
+    extern __shared__ __attribute__((aligned(16))) float lds_rows[];
+    float* const res = lds_rows;
+    float* const qs = res + D;
+    float* const qrow = qs + D;
+    float* const ws = qrow + D;
+    int* const wi = reinterpret_cast<int*>(ws + 8);
+    float* const rows = ws + 16;                                    // [K][PITCH]: one half of every code row (16-byte aligned: 3 D + 16 floats)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.x, N = B * T;
     const int b = n / T, t = n - b * T;
@@ -608,7 +612,7 @@ hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_o
         auto kern = rvq_ema_forward_rows_kernel<24>;
         static BigLdsOptIn opt;                           // per device: 104 KB of dynamic LDS at K = 512
         if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(N), dim3(512), (size_t)K * 52 * sizeof(float), s, z, books, q_out, idx_out, B, T, nb, K, update_residual);
+        hipLaunchKernelGGL(kern, dim3(N), dim3(512), ((size_t)K * 52 + 3 * 96 + 16) * sizeof(float), s, z, books, q_out, idx_out, B, T, nb, K, update_residual);
         return hipGetLastError();
     }
     if (N <= 256 && D % 4 == 0 && D <= 128 && !no_token_form) {
