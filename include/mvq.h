@@ -46,7 +46,8 @@ const char* mvq_last_error(void);
  *   0x1 MVQ_TIMING_BUILD, 0x2 MVQ_EXP (pieces of kernels compiled out: results are WRONG by construction), 0x4 MVQ_KGROUP /
  *   MVQ_KPREFETCH, 0x8 MVQ_NO_RES_PREFETCH, 0x10 MVQ_ASM_READS > 1 -- compile-time switches of tools/conv_microbench.py's timing
  *   builds (they do not compile without -DMVQ_TIMING_BUILD); 0x100 MVQ_NO_DMA, 0x200 MVQ_ROWFAST_MAX_KB, 0x400
- *   MVQ_NO_TOKEN_RVQ, 0x800 MVQ_LN_TILE32 -- environment overrides present (results stay correct, timings are not the product's);
+ *   MVQ_NO_TOKEN_RVQ, 0x800 MVQ_LN_TILE32, 0x1000 MVQ_LAT_MAX_TILES, 0x2000 MVQ_NO_DAC_RVQ_LAT, 0x4000 MVQ_NO_LN_LAT -- environment
+ *   overrides present (results stay correct, timings are not the product's);
  *   0x10000 (informational, not refused) the compiler-scheduled operand loop MVQ_ASM_READS=0.
  * The Python mirror refuses to load a library whose low 16 bits are non-zero unless MVQ_ALLOW_TIMING_BUILD=1;
  * bench.py prints the value in its line. */
@@ -504,6 +505,33 @@ int mvq_decoder_fwd_saving_f32(const mvq_stack* s, const float* z, float* y, voi
                                int batch, int t, void* stream);
 int mvq_decoder_bwd_input_f32(const mvq_stack* s, const void* saved, size_t saved_bytes, const float* gy, float* gz, void* workspace,
                               size_t workspace_bytes, int batch, int t, void* stream);
+
+/* ---- the auto-regressive chunk loop as ONE launch ------------------------------------------------------------------------------
+ * `for s in range(0, Tlat, AR_CHUNK_TOK)` of AllPredAR.forward_step (Training/compare_dacvsproposal_5.py:302-320) ==
+ * ProposedEval.encode_latents (Evaluation/dac_vcpwq_proposed6_latency.py:461-477) under no_grad: per 16-token chunk the
+ * CrossPredictor on the shift-by-one input, tanh(TokenNorm(zt - z_pred)) * clamp(scale), proj_down, ResidualVQEMA, proj_up, and the
+ * write into z_run that the next chunk's predictor reads.  One persistent kernel (csrc/ar_fused.hip): the stages of every chunk
+ * are separated by a grid-wide barrier instead of a launch boundary; each stage runs the arithmetic of the stand-alone entry points
+ * above (mvq_layernorm_c_sub_f32, mvq_conv1d_f32 with k = 1, mvq_attention_f32, mvq_rvq_ema_forward_f32), so results are
+ * bit-identical to the launch-per-stage sequence.  Launched cooperatively (the grid must be resident at once; the barrier gives up
+ * after a bounded wait and mvq_ar_check reports it).  Shapes: the reference's (c_lat 1024, FFN 2048, 8 heads, code dim 96, chunks of
+ * 16 tokens, K <= 512).  Linear weights are the packed images of mvq_conv1d_pack_f32 (k = 1); k_all / v_all are the audio keys /
+ * values of ALL chunks, token-folded [c_lat][batch * t_audio] (column b * t_audio + t) as the per-chunk calls use them
+ * (PosEnc restarts per chunk); pe[16][c_lat]; books [books_use][rvq_k][96].  z_run [batch, c_lat, t_lat] is written chunk by chunk;
+ * r_tokens [batch, 96, t_lat] (the tokens ema_step sees) and idx_out [books_use, batch, t_lat] (int32) are optional. */
+typedef struct mvq_ar_args {
+    int batch, t_lat, t_audio, tactile_only, books_use, rvq_k, c_lat, c_ff, code_dim, heads, chunk;
+    float ln_eps, tok_eps, scale;
+    const float *zt, *k_all, *v_all, *pe;
+    const float *lnq_g, *lnq_b, *wq, *wo, *lnf_g, *lnf_b, *w1, *b1, *w3, *b3;      /* CrossPredictor: ln_q, q_proj, out, ffn[0], ffn[1], ffn[3] */
+    const float *tok_g, *tok_b, *wd, *bd, *wu, *bu, *books;                       /* TokenNorm, proj_down, proj_up, vq.books */
+    float *z_run, *r_tokens;
+    int32_t* idx_out;
+} mvq_ar_args;
+size_t mvq_ar_workspace_bytes(int batch, int t_lat);
+int mvq_ar_latents_f32(const mvq_ar_args* args, void* workspace, size_t workspace_bytes, void* stream);
+/* synchronises `stream`, then: MVQ_OK when every grid barrier of the last call on this workspace completed */
+int mvq_ar_check(const void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,14 @@ class DecoderDesc(ctypes.Structure):
     _fields_ = [("input_channel", c_int), ("channels", c_int), ("n_rates", c_int), ("rates", c_int * 8), ("d_out", c_int), ("output_padding", c_int)]
 
 
+class ArArgs(ctypes.Structure):
+    """mvq_ar_args (include/mvq.h)."""
+    _fields_ = ([(n, c_int) for n in ("batch", "t_lat", "t_audio", "tactile_only", "books_use", "rvq_k", "c_lat", "c_ff", "code_dim", "heads", "chunk")]
+                + [(n, c_float) for n in ("ln_eps", "tok_eps", "scale")]
+                + [(n, c_void_p) for n in ("zt", "k_all", "v_all", "pe", "lnq_g", "lnq_b", "wq", "wo", "lnf_g", "lnf_b", "w1", "b1", "w3", "b3",
+                                           "tok_g", "tok_b", "wd", "bd", "wu", "bu", "books", "z_run", "r_tokens", "idx_out")])
+
+
 class ProfileEntry(ctypes.Structure):
     """mvq_profile_entry (include/mvq.h)."""
     _fields_ = [("kernel", ctypes.c_char * 96), ("seconds", ctypes.c_double), ("flops", ctypes.c_double), ("launches", c_int)]
@@ -130,6 +138,9 @@ EXPORTS = {
     "mvq_decoder_saved_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "mvq_decoder_fwd_saving_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "mvq_decoder_bwd_input_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "mvq_ar_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mvq_ar_latents_f32": (c_int, [ctypes.POINTER(ArArgs), c_void_p, c_size_t, c_void_p]),
+    "mvq_ar_check": (c_int, [c_void_p, c_void_p]),
 }
 
 

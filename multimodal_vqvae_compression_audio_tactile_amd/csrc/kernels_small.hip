@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include "det_math.hpp"
 #include "kernels_small.hpp"
+#include "ln_lat.hpp"
 
 namespace mvq {
 
@@ -479,6 +480,14 @@ __global__ __launch_bounds__(256) void layernorm_c_tile_kernel(
     }
 }
 
+// The latency form (ln_lat.hpp): 4 tokens per block, every operand requested up front, b128-fed chains.  Few tokens -- one AR chunk,
+// the keys / values of a handful of segments -- are what it is for; beyond a block per CU the 8-token tiles above take over.
+__global__ __launch_bounds__(256) void layernorm_c_lat_kernel(const LnIo io, int B, int C, int T)
+{
+    extern __shared__ __attribute__((aligned(16))) float ln_lat_smem[];
+    ln_lat_task(io, blockIdx.x, B, T, C, ln_lat_smem, threadIdx.x, [](const float* p) { return *p; });
+}
+
 __global__ void layernorm_c_kernel(const float* __restrict__ x, const float* __restrict__ pe,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ y, int B, int C, int T, size_t sb, size_t sc,
@@ -537,6 +546,18 @@ hipError_t launch_layernorm_c(const float* x, const float* pe, const float* gamm
         // of a 256-segment batch where the 32-token tile (128 KB, one block per CU) put 600 -- round 4: 2.3 -> see DESIGN 6c ms per step.
         static const bool ln32 = getenv("MVQ_LN_TILE32") != nullptr;       // A/B knob (reported by mvq_build_flags)
         if (ln32) note_env_override(0x800);
+        static const bool no_lat = getenv("MVQ_NO_LN_LAT") != nullptr;     // A/B knob (reported by mvq_build_flags)
+        if (no_lat) note_env_override(0x4000);
+        if (n <= 1024 && C % 64 == 0 && ln_lat_lds_floats(C) * sizeof(float) <= 64 * 1024 && !no_lat && !ln32) {
+            LnIo io{};
+            io.x = x; io.x_sb = sb; io.x_sc = sc;
+            io.sub = sub; io.sub_sb = sb; io.sub_sc = sc;
+            io.pe = pe; io.gamma = gamma; io.beta = beta;
+            io.y0 = y; io.y0_sb = sb; io.y0_sc = sc;
+            io.eps = eps; io.post_scale = post_scale; io.do_tanh = do_tanh;
+            hipLaunchKernelGGL(layernorm_c_lat_kernel, dim3((n + LN_LAT_TOK - 1) / LN_LAT_TOK), dim3(256), ln_lat_lds_floats(C) * sizeof(float), s, io, B, C, T);
+            return hipGetLastError();
+        }
         if (n > 64 && !ln32 && ((size_t)C * 8 + 16) * sizeof(float) <= 64 * 1024)
             hipLaunchKernelGGL(layernorm_c_tile_kernel<8>, dim3((n + 7) / 8), dim3(256), ((size_t)C * 8 + 16) * sizeof(float), s,
                                x, pe, gamma, beta, y, B, C, T, sb, sc, eps, do_tanh, post_scale, sub);

@@ -7,6 +7,7 @@ autocast, Evaluation/compare_dacvsproposal_5_eval.py:441) are widened to fp32: t
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -513,6 +514,39 @@ def attention_kv_slice(q, k_all, v_all, heads, folded_batch, s, tk):
     check(_lib.lib().mvq_attention_f32(q.data_ptr(), k_all.data_ptr() + 4 * s, v_all.data_ptr() + 4 * s, ctx.data_ptr(),
                                        B, heads, C // heads, Tq, tk, Tq, B * Tq, Ta, B * Ta, _stream()), "mvq_attention_f32")
     return ctx
+
+
+_AR_CHECKED = set()
+
+
+def ar_latents_fused(zt, z_run, *, k_all, v_all, t_audio, pe, ln_q, wq, wo, ln_f, w1, b1, w3, b3, ln_eps, tok, tok_eps, scale,
+                     wd, bd, wu, bu, books, books_use, heads, c_ff, code_dim, r_tokens=None, idx_out=None, tactile_only=False, chunk=16):
+    """The whole chunked AR loop as ONE persistent kernel (csrc/ar_fused.hip: mvq_ar_latents_f32): zt[B,C,Tlat] -> z_run[B,C,Tlat]
+    (written in place), optionally r_tokens[B,96,Tlat] and idx_out[nb,B,Tlat] (int32).  ``k_all`` / ``v_all``: token-folded K / V
+    of all chunks ([1,C,B*t_audio], CrossPredictor.keys_values) or None; the w* are K-major packed 1x1 weights (pack_conv1d);
+    ln_q / ln_f / tok = (weight, bias).  Same bits as the launch-per-stage path (tests/test_gpu_ar_fused.py)."""
+    zt = _dev(zt, "zt")
+    B, C, Tl = zt.shape
+    nb_all, K = (books.shape[0], books.shape[1]) if books is not None else (0, 1)
+    nb = nb_all if books_use is None else max(0, min(int(books_use), nb_all))
+    a = _lib.ArArgs()
+    a.batch, a.t_lat, a.t_audio, a.tactile_only, a.books_use, a.rvq_k = B, Tl, int(t_audio), int(bool(tactile_only)), nb, K
+    a.c_lat, a.c_ff, a.code_dim, a.heads, a.chunk = C, int(c_ff), int(code_dim), int(heads), int(chunk)
+    a.ln_eps, a.tok_eps, a.scale = float(ln_eps), float(tok_eps), float(scale)
+    a.zt, a.z_run, a.r_tokens, a.idx_out = zt.data_ptr(), z_run.data_ptr(), _p(r_tokens), _p(idx_out)
+    a.k_all, a.v_all, a.pe = _p(k_all), _p(v_all), _p(pe)
+    (a.lnq_g, a.lnq_b), (a.lnf_g, a.lnf_b), (a.tok_g, a.tok_b) = map(lambda t: (_p(t[0]), _p(t[1])), (ln_q, ln_f, tok))
+    a.wq, a.wo, a.w1, a.b1, a.w3, a.b3 = _p(wq), _p(wo), _p(w1), _p(b1), _p(w3), _p(b3)
+    a.wd, a.bd, a.wu, a.bu, a.books = _p(wd), _p(bd), _p(wu), _p(bu), _p(books)
+    L = _lib.lib()
+    nbytes = L.mvq_ar_workspace_bytes(B, Tl)
+    ws = torch.empty(max(nbytes, 4), device=zt.device, dtype=torch.uint8)
+    check(L.mvq_ar_latents_f32(ctypes.byref(a), ws.data_ptr(), nbytes, _stream()), "mvq_ar_latents_f32")
+    key = (B, Tl, zt.device.index, bool(tactile_only))
+    if key not in _AR_CHECKED:            # co-residency of the persistent grid is a property of the shape: verified on its first use
+        check(L.mvq_ar_check(ws.data_ptr(), _stream()), "mvq_ar_check")
+        _AR_CHECKED.add(key)
+    return z_run
 
 
 def gelu(x):

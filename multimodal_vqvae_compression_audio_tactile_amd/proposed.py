@@ -228,6 +228,9 @@ class _ProposedBase(nn.Module):
             Ta = min(qa.shape[-1], Tlat)                                      # audio may be shorter (whole-file mode)
             if Ta > 0:                                                        # K, V of all chunks up front (3 launches)
                 kv_all = self.predict.keys_values(ops.fold_time_slice(qa, 0, Ta), B, AR_CHUNK_TOK)
+        if self._ar_fused_wanted(zt, books):
+            return self._ar_latents_fused(zt, z_run, r_tokens, kv_all, 0 if tactile_only else min(qa.shape[-1], Tlat), books, books_use,
+                                          tactile_only, want_indices)
         zt_prev, zp_n = None, -1      # the shift-by-one input: all zero except column 0 of each item (s > 0), so one zeroed
         for s in range(0, Tlat, AR_CHUNK_TOK):                               # buffer per chunk width serves every chunk
             e = min(Tlat, s + AR_CHUNK_TOK)
@@ -261,6 +264,40 @@ class _ProposedBase(nn.Module):
                 ops.unfold_into_(r_tokens, s, rD, B)
         if want_indices:
             return z_run, r_tokens, torch.cat(idx_all, dim=2) if idx_all else torch.zeros(0, B, Tlat, dtype=torch.int64)
+        return z_run, r_tokens
+
+    # The loop as ONE persistent kernel (csrc/ar_fused.hip: eleven stages per chunk between grid-wide barriers), for up to this many
+    # segments.  OFF by default (0): measured at the reference's operating points (tools/ar_fused_ab.py, gpurun_out/f8) it is bit-equal
+    # to the launch-per-stage loop and SLOWER -- 1.22 against 0.99 ms for one segment, 1.74 against 1.09 ms for six.  The stages are
+    # 5-45 us of dependent chain each; at that length the command processor already has the next launch queued behind the running
+    # kernel, so a launch boundary costs less than the ~4 us a grid barrier (a device-scope atomic, an L2 write-back and an
+    # invalidate across eight XCDs) does.  Kept as an opt-in (MVQ_AR_FUSED_MAX_BATCH) with its parity tests: it is the place where
+    # per-stage clocks can be read (MVQ_AR_TIMING=1), which is how the LayerNorm / GEMM-epilogue round trips of round 5 were found.
+    AR_FUSED_MAX_BATCH = int(_dac.HOST_ENV_SEEN.get("MVQ_AR_FUSED_MAX_BATCH", "0"))
+
+    def _ar_fused_wanted(self, zt, books):
+        p = self.predict
+        return (zt.is_cuda and 0 < zt.shape[0] <= self.AR_FUSED_MAX_BATCH and ops.get_arith() == "f32"
+                and not torch.cuda.is_current_stream_capturing()            # a cooperative launch is not capturable
+                and zt.shape[1] == 1024 and p.h == 8 and p.ffn[1].out_features == 2048 and CODE_DIM == 96 and p.ln_q.eps == p.ffn[0].eps
+                and (books is None or (books.shape[1] <= 512 and books.shape[2] == CODE_DIM)))
+
+    def _ar_latents_fused(self, zt, z_run, r_tokens, kv_all, t_audio, books, books_use, tactile_only, want_indices):
+        B, _, Tlat = zt.shape
+        p, L, ln = self.predict, self.predict._lin, self.tokennorm.ln
+        nb = 0 if books is None else (books.shape[0] if books_use is None else max(0, min(int(books_use), books.shape[0])))
+        idx = torch.empty(nb, B, Tlat, device=zt.device, dtype=torch.int32) if want_indices else None
+        det = lambda t: None if t is None else t.detach()
+        ops.ar_latents_fused(
+            zt.contiguous(), z_run, k_all=None if kv_all is None else kv_all[0], v_all=None if kv_all is None else kv_all[1],
+            t_audio=t_audio if kv_all is not None else 0, pe=p.pos.pe, ln_q=(det(p.ln_q.weight), det(p.ln_q.bias)),
+            wq=L["q"].wp(), wo=L["o"].wp(), ln_f=(det(p.ffn[0].weight), det(p.ffn[0].bias)), w1=L["f1"].wp(), b1=det(p.ffn[1].bias),
+            w3=L["f3"].wp(), b3=det(p.ffn[3].bias), ln_eps=p.ln_q.eps, tok=(det(ln.weight), det(ln.bias)), tok_eps=ln.eps,
+            scale=self._scale_value(), wd=self._pd.wp(), bd=det(self.proj_down.bias), wu=self._pu.wp(), bu=det(self.proj_up.bias),
+            books=books, books_use=books_use, heads=p.h, c_ff=p.ffn[1].out_features, code_dim=CODE_DIM, r_tokens=r_tokens, idx_out=idx,
+            tactile_only=tactile_only, chunk=AR_CHUNK_TOK)
+        if want_indices:
+            return z_run, r_tokens, idx.long()
         return z_run, r_tokens
 
     # The two encoder branches (qa = A_QUANT(A_ENC(a)), zt = T_ENC(t)) are independent; up to this many segments they run on two

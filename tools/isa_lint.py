@@ -193,7 +193,9 @@ def lint_function(name: str, insns: list[tuple[int, str, str]]) -> list[str]:
                     first = args.split(",")[0]
                     dst = frozenset(regs(first, VREG, "v") | regs(first, AREG, "a"))
                 q.append((dst, addr if dst else 0))            # stores only count; collapsing them keeps the state space small
-                q = q[-16:]                                     # lgkmcnt is a 4-bit counter
+                q = q[-15:]                                     # lgkmcnt is a 4-bit counter: at most 15 operations are outstanding, the
+                                                                # 16th cannot issue before the oldest has returned (LLVM's SIInsertWaitcnts
+                                                                # relies on the same bound: it never waits for an operation 15 issues back)
         addr, op, args = insns[end - 1]
         succ = []
         if op == "s_branch":
