@@ -238,17 +238,23 @@ def vq_lds_table():
                        "kernels_unchanged_since_profile": bool(meta.get("csrc_sha16")) and meta.get("csrc_sha16") == now}}
 
 
-def batch_sweep(net, synth, dev, tact, gflop_per_segment, headline_batch, y_headline):
+def batch_sweep(net, synth, dev, tact, gflop_per_segment, headline_batch, y_headline, a_headline, t_headline):
     """The reference's own operating points next to the headline (B in {1, 6, 64, 256}; the eval
     loader and the training loop run batches of 6, Evaluation/compare_dacvsproposal_5_eval.py:487-489, Training/...5.py:62): the
     same forward_eval on the first B segments of the headline batch, 3 warm-ups + timed repeats with the inputs resident, ms per
     step, segments/s and the algorithmic fraction of the fp32 MFMA peak -- each under the headline's rule: rows of the B-segment
     output must equal the same segments' rows of the headline output bit for bit (batch independence), else the run fails."""
     out = {}
-    a_all = synth.audio_segments(max(64, 1), seed=7).to(dev); t_all = synth.tactile_segments(max(64, 1), seed=7).to(dev)
+    # Rows 0..B-1 of the HEADLINE's own input tensors whenever the headline batch has them.  (A fresh draw of another size is not the
+    # same data: synth shapes its noise through an FFT whose rounding can depend on the batch it is called with -- round 5,
+    # `--batch 6`: every comparison failed on inputs that differed in the last place, gpurun_out/f9small.)  A sweep size beyond the
+    # headline batch gets a draw of its own and is timed but not compared.
+    big = max(64, headline_batch)
+    a_all, t_all = (a_headline, t_headline) if headline_batch >= 64 else (synth.audio_segments(big, seed=7).to(dev), synth.tactile_segments(big, seed=7).to(dev))
     fwd = (lambda a, t: net.forward_eval_tactile_only(t, books_use=None)) if tact else (lambda a, t: net.forward_eval(a, t, books_use=None))
     for B in (1, 6, 64):
-        a, t = a_all[:B].contiguous(), t_all[:B].contiguous()
+        src_a, src_t = (a_headline, t_headline) if B <= headline_batch else (a_all, t_all)
+        a, t = src_a[:B].contiguous(), src_t[:B].contiguous()
         for _ in range(3):
             y = fwd(a, t)
         torch.cuda.synchronize()
@@ -258,12 +264,12 @@ def batch_sweep(net, synth, dev, tact, gflop_per_segment, headline_batch, y_head
             y = fwd(a, t)
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / reps
-        n = min(B, headline_batch, y_headline.shape[0])
-        same = bool(torch.equal(y[:n], y_headline[:n])) if y.shape[1:] == y_headline.shape[1:] else False
+        n = min(B, y_headline.shape[0])
+        same = None if B > headline_batch else (bool(torch.equal(y[:n], y_headline[:n])) if y.shape[1:] == y_headline.shape[1:] else False)
         tf = B * gflop_per_segment / ms                          # GFLOP / ms = TFLOP/s
         out[f"B{B}"] = {"ms_per_step": ms, "segments_per_s": 1e3 * B / ms, "path_tflops": tf, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS,
                         "rows_bit_equal_to_headline_batch": same, "repeats": reps}
-    out["note"] = ("same synthetic segments as rows 0..B-1 of the headline batch (seed 7, rank 0); eager calls, inputs resident, "
+    out["note"] = ("rows 0..B-1 of the headline batch's own inputs (a sweep size beyond the headline batch: its own draw, not compared: null); eager calls, inputs resident, "
                    "device synchronised around the timed repeats")
     return out
 
@@ -590,7 +596,7 @@ def main():
                 line["vq"] = vq
         if world == 1 and not train and not args.no_sweep and args.arith == "f32":
             try:
-                line["batch_sweep"] = batch_sweep(net, synth, dev, tact, GFLOP_PER_SEGMENT[args.workload], B, y)
+                line["batch_sweep"] = batch_sweep(net, synth, dev, tact, GFLOP_PER_SEGMENT[args.workload], B, y, a, t)
             except Exception as ex:
                 line["batch_sweep"] = {"error": repr(ex)}
         if world == 1 and not train and not args.no_latency:
@@ -606,7 +612,7 @@ def main():
             except Exception as ex:       # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "token-frames/s", "cores": torch.get_num_threads(),
                                         "kind": "port", "sample": f"failed: {ex!r}"}
-        sweep_ok = all(v.get("rows_bit_equal_to_headline_batch", True) for v in line.get("batch_sweep", {}).values() if isinstance(v, dict))
+        sweep_ok = all(v.get("rows_bit_equal_to_headline_batch", True) is not False for v in line.get("batch_sweep", {}).values() if isinstance(v, dict))
         if not sweep_ok:
             print("[bench] batch sweep: a small-batch output differs from the same segments of the headline batch", file=sys.stderr, flush=True)
             spot_ok = False

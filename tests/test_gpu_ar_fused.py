@@ -1,7 +1,7 @@
 """The persistent AR-loop kernel (csrc/ar_fused.hip, mvq_ar_latents_f32) against the launch-per-stage loop it replaces at small
 batch sizes: same bits for z_run, the tokens the EMA update sees and the code indices, over the shapes the reference meets
-(Training/compare_dacvsproposal_5.py:302-320 == Evaluation/dac_vcpwq_proposed6_latency.py:461-477).  The end-to-end parity
-tests (test_gpu_parity_e2e.py, B = 1-2) run the fused loop against the C oracle."""
+(Training/compare_dacvsproposal_5.py:302-320 == Evaluation/dac_vcpwq_proposed6_latency.py:461-477), and end to end against the C
+oracle.  The fused loop is an opt-in (proposed.py: AR_FUSED_MAX_BATCH, default 0): the tests switch it on."""
 import numpy as np
 import pytest
 import torch
@@ -66,6 +66,18 @@ def test_fused_loop_tactile_only(nets, dev):
     _, zt = _latents(4, 75, 1, 9, dev)
     fused, plain = _both(net, None, zt, tactile_only=True, want_tokens=True)
     assert torch.equal(fused[0], plain[0]) and torch.equal(fused[1], plain[1])
+
+
+def test_fused_loop_end_to_end_against_the_oracle(orc, dev, monkeypatch):
+    from multimodal_vqvae_compression_audio_tactile_amd import build_proposed, synth
+    sd = synth.proposed_model_state(13, rvq_books=2, rvq_embed=128)
+    net = build_proposed(sd, rvq_books=2, rvq_embed=128, device=dev)
+    monkeypatch.setattr(net, "AR_FUSED_MAX_BATCH", 8)
+    a = synth.audio_segments(1, seed=4, T=320 * 20)            # 20 audio tokens under 35 tactile ones: chunk 2 sees Tk = 4, chunk 3 Tk = 0
+    t = synth.tactile_segments(1, seed=4, T=320 * 35)
+    want = orc.proposed_encode_latents({k: v.numpy() for k, v in sd.items()}, a.numpy(), t.numpy())
+    got = net.encode_latents(a.to(dev), t.to(dev))
+    assert np.array_equal(got.cpu().numpy(), want)
 
 
 def test_fused_loop_selection(nets, dev, monkeypatch):

@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/b1dec" -- python3 
 cp "$(ls $OUT/b1dec/*/*kernel_stats.csv | tail -1)" "$OUT/kernel_stats_B1_decode.csv" || exit 15
 python3 tools/trace_gaps.py "$(ls $OUT/b1dec/*/*kernel_trace.csv | tail -1)" > "$OUT/gaps_B1_decode.json" || exit 16
 echo "[3/6] B=6 inference trace"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/b6inf" -- python3 bench.py --batch 6 --steps 20 --warmup 3 --no-cpu-baseline --no-latency --no-kernel-events > "$OUT/bench_B6_under_rocprof.json" 2> "$OUT/b6inf.err" || exit 21
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/b6inf" -- python3 bench.py --batch 6 --steps 20 --warmup 3 --no-cpu-baseline --no-latency --no-kernel-events --no-sweep > "$OUT/bench_B6_under_rocprof.json" 2> "$OUT/b6inf.err" || exit 21
 cp "$(ls $OUT/b6inf/*/*kernel_stats.csv | tail -1)" "$OUT/kernel_stats_B6_inference.csv" || exit 22
 python3 tools/trace_gaps.py "$(ls $OUT/b6inf/*/*kernel_trace.csv | tail -1)" > "$OUT/gaps_B6_inference.json" || exit 23
 echo "[4/6] B=6 training-step trace"
