@@ -970,164 +970,161 @@ hipError_t launch_dac_rvq_prepare(const float* cb, float* cbn, float* cn2, int n
 }
 
 // ------------------------------------------------------------------------------------------------
-// Latency form of the DAC quantiser (round 5): 128 THREADS PER TOKEN, two tokens per block, nothing staged in LDS.
+// Latency form of the DAC quantiser (round 5): ONE TOKEN PER BLOCK, 256 threads, nothing staged in LDS, and every operand of stage
+// s + 1 requested at the top of stage s.
 // profiles/r05_kernel_stats_B1_encode_before.csv: dac_rvq_kernel takes 598 us for the 75 tokens of one segment -- 19 us per stage on
 // 5 of the 256 CUs: a block copies ~100 KB of stage weights and codebook into LDS per stage, and a thread then walks 8 in_proj
 // chains of 64, 64 codes and 64 out_proj channels one after another.  The contract fixes the CHAINS (in_proj: 16 block partials of
 // C/16 channels per codebook dimension, added in block order; out_proj: an 8-long chain per channel; scores: an 8-long chain per
-// code), not who runs them: here a token's 128 threads take ONE partial chain, K/128 codes and C/128 channels each, straight from
-// global memory (L2-resident: every block reads the same 100 KB per stage), with every row a stage needs requested ahead of
-// the phase that uses it -- the next stage's in_proj rows before this stage's out_proj, the code rows (normalised for the search,
-// raw for the straight-through value) and out_proj rows at the top of the stage -- so no phase starts by waiting for L2, and
-// the winner publishes the raw row it already holds.  Needs the prepared codebook (mvq_dac_rvq_prepare_f32).
-// LDS: res[2][C] | part[2][16][8] | ze[2][8] | pre[2][8] | red
+// code), not who runs them: here the token's first 128 threads take ONE partial chain each, and every thread K/256 codes and C/256
+// channels, straight from global memory (L2-resident: every block reads the same 136 KB per stage).
+// The first cut (two tokens per block, rows requested one PHASE ahead) still took 8.2 us per stage (gpurun_out/r05bsmall,
+// profiles/r05_kernel_stats_B1_encode_mid.csv: 262 us): a phase is ~0.2 us of arithmetic, an L2 round trip several times that, so
+// every phase still began by waiting.  With one token per block a thread's share of a stage is 42 sixteen-byte rows (168 VGPRs);
+// a block per CU has 512 VGPRs per lane, so TWO stages fit and the next stage's rows travel during the whole current stage.
+// Needs the prepared codebook (mvq_dac_rvq_prepare_f32).  LDS: res[C] | part[16][8] | ze[8] | pre[8] | red
 // ------------------------------------------------------------------------------------------------
-template <int CPT, int KJ>    // C = 16 * CPT channels, K = 128 * KJ codes, Dc = 8
-__global__ __launch_bounds__(256) void dac_rvq_lat_kernel(
+template <int CPT, int KJ>    // C = 16 * CPT channels, K = 256 * KJ codes, Dc = 8
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dac_rvq_lat_kernel(
     const float* __restrict__ z, const float* __restrict__ in_w, const float* __restrict__ in_b,
     const float* __restrict__ cb, const float* __restrict__ out_w, const float* __restrict__ out_b,
     float* __restrict__ zq, int32_t* __restrict__ codes, float* __restrict__ latents,
     const int32_t* __restrict__ nq_item, int B, int T, int nq,
     const float* __restrict__ cbn_pre, const float* __restrict__ cn2_pre)
 {
-    constexpr int C = 16 * CPT, Dc = 8, K = 128 * KJ, CO = C / 128, IV = CPT / 4;
+    constexpr int C = 16 * CPT, Dc = 8, K = 256 * KJ, CO = C / 256, IV = CPT / 4;
+    static_assert(C % 256 == 0 && CPT % 4 == 0, "a thread owns C / 256 channels; in_proj pieces are 16-byte rows");
     typedef float v4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) float res_s[2][C];
-    __shared__ float part[2][16][Dc], ze[2][Dc], pre[2][Dc], red_s[2][2];
-    __shared__ int red_i[2][2];
-    const int tid = threadIdx.x, tl = tid & 127, tk = tid >> 7, lane = tid & 63, wv = (tid >> 6) & 1;
-    const int N = B * T;
-    const int n = blockIdx.x * 2 + tk;
-    const bool live = n < N;
-    const int bb = live ? n / T : 0, tt = live ? n - bb * T : 0;
-    const int lim = (nq_item && live) ? nq_item[bb] : nq;
-    const int g = tl >> 3, d_in = tl & 7;                          // in_proj role: block partial g of codebook dimension d_in
-    const int c0 = tl * CO;                                        // out_proj role: channels c0 .. c0 + CO - 1
+    __shared__ __attribute__((aligned(16))) float res_s[C];
+    __shared__ float part[16][Dc], ze[Dc], pre[Dc], red_s[4];
+    __shared__ int red_i[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = blockIdx.x;                                      // grid = B * T tokens
+    const int bb = n / T, tt = n - bb * T;
+    const int lim = nq_item ? nq_item[bb] : nq;
+    const int g = tid >> 3, d_in = tid & 7;                        // in_proj role (threads 0..127): block partial g of codebook dimension d_in
+    const bool inproj = tid < 128;
+    const int c0 = tid * CO;                                       // out_proj role: channels c0 .. c0 + CO - 1
 
     float resr[CO], acc[CO];
 #pragma unroll
     for (int j = 0; j < CO; ++j) {
         acc[j] = 0.0f;
-        resr[j] = live ? z[((size_t)bb * C + c0 + j) * T + tt] : 0.0f;
-        res_s[tk][c0 + j] = resr[j];
+        resr[j] = z[((size_t)bb * C + c0 + j) * T + tt];
+        res_s[c0 + j] = resr[j];
     }
-    // Loads are requested one phase ahead of their use and never more than ~56 at a time (the wave's vector-memory counter holds
-    // 63: with every row of a stage requested at its top -- 90 loads -- the in_proj phase had to wait for most of them, one L2
-    // latency per stage; gpurun_out/r05bsmall: 8.2 us per stage):
-    //   in_proj rows of stage s+1 and the out_proj rows behind the search | code rows (normalised) at the top | raw code rows
-    //   behind in_proj (only the winner's is used, after the arg-max).
-    v4 iw[IV];                                                     // in_proj row piece of (stage, d_in, block g): CPT floats
-    auto fetch_in = [&](int st) __attribute__((always_inline)) {
-        const float* wr = in_w + ((size_t)st * Dc + d_in) * C + g * CPT;
-#pragma unroll
-        for (int u = 0; u < IV; ++u) iw[u] = *reinterpret_cast<const v4*>(wr + 4 * u);
+    struct StageOps {
+        v4 iw[IV];                                                 // in_proj row piece of (stage, d_in, block g): CPT floats
+        v4 sw[KJ][2], rw[KJ][2];                                   // codes k = tid + 256 j: normalised row (search), raw row (straight-through value)
+        v4 ow[CO][2];                                              // out_proj rows of the owned channels
+        float cn2v[KJ], obv[CO], inb;
     };
-    fetch_in(0);
-    for (int st = 0; st < nq; ++st) {
-        v4 sw[KJ][2], rw[KJ][2], ow[CO][2];
-        float cn2v[KJ], obv[CO];
+    auto fetch = [&](StageOps& P, int st) __attribute__((always_inline)) {
+        if (inproj) {
+            const float* wr = in_w + ((size_t)st * Dc + d_in) * C + g * CPT;
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) {                             // codes k = tl + 128 j: normalised rows + squared norms
-            const size_t k = (size_t)st * K + tl + 128 * j;
-            sw[j][0] = *reinterpret_cast<const v4*>(cbn_pre + k * Dc); sw[j][1] = *reinterpret_cast<const v4*>(cbn_pre + k * Dc + 4);
-            cn2v[j] = cn2_pre[k];
+            for (int u = 0; u < IV; ++u) P.iw[u] = *reinterpret_cast<const v4*>(wr + 4 * u);
         }
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+            const size_t k = (size_t)st * K + tid + 256 * j;
+            P.sw[j][0] = *reinterpret_cast<const v4*>(cbn_pre + k * Dc); P.sw[j][1] = *reinterpret_cast<const v4*>(cbn_pre + k * Dc + 4);
+            P.rw[j][0] = *reinterpret_cast<const v4*>(cb + k * Dc); P.rw[j][1] = *reinterpret_cast<const v4*>(cb + k * Dc + 4);
+            P.cn2v[j] = cn2_pre[k];
+        }
+#pragma unroll
+        for (int j = 0; j < CO; ++j) {
+            const float* wr = out_w + ((size_t)st * C + c0 + j) * Dc;
+            P.ow[j][0] = *reinterpret_cast<const v4*>(wr); P.ow[j][1] = *reinterpret_cast<const v4*>(wr + 4);
+            P.obv[j] = out_b[(size_t)st * C + c0 + j];
+        }
+        P.inb = tid < Dc ? in_b[(size_t)st * Dc + tid] : 0.0f;
+    };
+    auto stage = [&](const StageOps& P, StageOps& Pn, int st) __attribute__((always_inline)) {
+        if (st + 1 < nq) fetch(Pn, st + 1);                        // in flight for this whole stage
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                           // res_s holds this stage's residual
-        {   // in_proj block partial: channels g*CPT .. +CPT-1 ascending, from +0
-            const float* rr = &res_s[tk][g * CPT];
+        if (inproj) {   // in_proj block partial: channels g*CPT .. +CPT-1 ascending, from +0
+            const float* rr = &res_s[g * CPT];
             float p = 0.0f;
 #pragma unroll
             for (int u = 0; u < IV; ++u) {
                 const v4 r4 = *reinterpret_cast<const v4*>(rr + 4 * u);
-                p = dfma(iw[u].x, r4.x, p); p = dfma(iw[u].y, r4.y, p); p = dfma(iw[u].z, r4.z, p); p = dfma(iw[u].w, r4.w, p);
+                p = dfma(P.iw[u].x, r4.x, p); p = dfma(P.iw[u].y, r4.y, p); p = dfma(P.iw[u].z, r4.z, p); p = dfma(P.iw[u].w, r4.w, p);
             }
-            part[tk][g][d_in] = p;
+            part[g][d_in] = p;
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < KJ; ++j) {                             // raw rows of the same codes (the straight-through value of the winner)
-            const size_t k = (size_t)st * K + tl + 128 * j;
-            rw[j][0] = *reinterpret_cast<const v4*>(cb + k * Dc); rw[j][1] = *reinterpret_cast<const v4*>(cb + k * Dc + 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        if (tl < Dc) {                                             // the 16 block partials in block order, + bias
-            float a = part[tk][0][tl];
+        if (tid < Dc) {                                            // the 16 block partials in block order, + bias
+            float a = part[0][tid];
 #pragma unroll
-            for (int gg = 1; gg < 16; ++gg) a = a + part[tk][gg][tl];
-            const float v = a + in_b[(size_t)st * Dc + tl];
-            ze[tk][tl] = v;
-            if (live) latents[((size_t)bb * nq * Dc + (size_t)st * Dc + tl) * T + tt] = v;
+            for (int gg = 1; gg < 16; ++gg) a = a + part[gg][tid];
+            const float v = a + P.inb;
+            ze[tid] = v;
+            latents[((size_t)bb * nq * Dc + (size_t)st * Dc + tid) * T + tt] = v;
         }
         __syncthreads();
         float bs = -__builtin_inff(); int bi = 0x7fffffff;
-        {   // F.normalize over Dc (every thread of the token computes the same values), then this thread's codes, ascending
+        v4 br0 = P.rw[0][0], br1 = P.rw[0][1];                     // raw row of this thread's best code so far (the winner publishes its own)
+        {   // F.normalize over Dc (every thread computes the same values), then this thread's codes, ascending
             float ss = 0.0f;
 #pragma unroll
-            for (int d = 0; d < Dc; ++d) { const float v = ze[tk][d]; ss = dfma(v, v, ss); }
+            for (int d = 0; d < Dc; ++d) { const float v = ze[d]; ss = dfma(v, v, ss); }
             const float den = __builtin_fmaxf(__builtin_sqrtf(ss), 1e-12f);
             float s2 = 0.0f, ev[Dc];
 #pragma unroll
-            for (int d = 0; d < Dc; ++d) { ev[d] = ze[tk][d] / den; s2 = dfma(ev[d], ev[d], s2); }
+            for (int d = 0; d < Dc; ++d) { ev[d] = ze[d] / den; s2 = dfma(ev[d], ev[d], s2); }
 #pragma unroll
             for (int j = 0; j < KJ; ++j) {
                 float dot = 0.0f;
-                dot = dfma(ev[0], sw[j][0].x, dot); dot = dfma(ev[1], sw[j][0].y, dot); dot = dfma(ev[2], sw[j][0].z, dot); dot = dfma(ev[3], sw[j][0].w, dot);
-                dot = dfma(ev[4], sw[j][1].x, dot); dot = dfma(ev[5], sw[j][1].y, dot); dot = dfma(ev[6], sw[j][1].z, dot); dot = dfma(ev[7], sw[j][1].w, dot);
-                const float dist = (s2 - 2.0f * dot) + cn2v[j];
+                dot = dfma(ev[0], P.sw[j][0].x, dot); dot = dfma(ev[1], P.sw[j][0].y, dot); dot = dfma(ev[2], P.sw[j][0].z, dot); dot = dfma(ev[3], P.sw[j][0].w, dot);
+                dot = dfma(ev[4], P.sw[j][1].x, dot); dot = dfma(ev[5], P.sw[j][1].y, dot); dot = dfma(ev[6], P.sw[j][1].z, dot); dot = dfma(ev[7], P.sw[j][1].w, dot);
+                const float dist = (s2 - 2.0f * dot) + P.cn2v[j];
                 const float sc = -dist;
-                if (sc > bs) { bs = sc; bi = tl + 128 * j; }
+                if (sc > bs) { bs = sc; bi = tid + 256 * j; br0 = P.rw[j][0]; br1 = P.rw[j][1]; }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < CO; ++j) {                             // out_proj rows + bias of the owned channels; then the next stage's in_proj rows
-            const float* wr = out_w + ((size_t)st * C + c0 + j) * Dc;
-            ow[j][0] = *reinterpret_cast<const v4*>(wr); ow[j][1] = *reinterpret_cast<const v4*>(wr + 4);
-            obv[j] = out_b[(size_t)st * C + c0 + j];
-        }
-        if (st + 1 < nq) fetch_in(st + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        wave_argmax(bs, bi);                                       // a wave holds 64 threads of ONE token
-        if (lane == 0) { red_s[tk][wv] = bs; red_i[tk][wv] = bi; }
+        wave_argmax(bs, bi);
+        if (lane == 0) { red_s[wv] = bs; red_i[wv] = bi; }
         __syncthreads();
         {
-            float cs = red_s[tk][0]; int id = red_i[tk][0];
-            amax_combine(cs, id, red_s[tk][1], red_i[tk][1]);
-            if (id < 0 || id >= K) id = 0;
-            if (tl == (id & 127)) {                                // the thread that holds the winning code's raw row
-                const int jw = id >> 7;
-                v4 r0 = rw[0][0], r1 = rw[0][1];
+            float cs = red_s[0]; int id = red_i[0];
 #pragma unroll
-                for (int j = 1; j < KJ; ++j) if (j == jw) { r0 = rw[j][0]; r1 = rw[j][1]; }
+            for (int w = 1; w < 4; ++w) amax_combine(cs, id, red_s[w], red_i[w]);
+            if (id < 0 || id >= K) id = 0;
+            if (tid == (id & 255)) {                               // the thread that holds the winning code: its own best IS the winner
+                const v4 r0 = br0, r1 = br1;
                 const float raw[Dc] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-                for (int d = 0; d < Dc; ++d) { const float zv = ze[tk][d]; pre[tk][d] = zv + (raw[d] - zv); }
-                if (live) codes[((size_t)bb * nq + st) * T + tt] = id;
+                for (int d = 0; d < Dc; ++d) { const float zv = ze[d]; pre[d] = zv + (raw[d] - zv); }
+                codes[((size_t)bb * nq + st) * T + tt] = id;
             }
         }
         __syncthreads();
         {   // out_proj: an 8-long chain per owned channel, + bias; accumulate (under the item's stage limit) and update the residual
             float pv[Dc];
 #pragma unroll
-            for (int d = 0; d < Dc; ++d) pv[d] = pre[tk][d];
+            for (int d = 0; d < Dc; ++d) pv[d] = pre[d];
 #pragma unroll
             for (int j = 0; j < CO; ++j) {
                 float a = 0.0f;
-                a = dfma(ow[j][0].x, pv[0], a); a = dfma(ow[j][0].y, pv[1], a); a = dfma(ow[j][0].z, pv[2], a); a = dfma(ow[j][0].w, pv[3], a);
-                a = dfma(ow[j][1].x, pv[4], a); a = dfma(ow[j][1].y, pv[5], a); a = dfma(ow[j][1].z, pv[6], a); a = dfma(ow[j][1].w, pv[7], a);
-                const float zqi = a + obv[j];
+                a = dfma(P.ow[j][0].x, pv[0], a); a = dfma(P.ow[j][0].y, pv[1], a); a = dfma(P.ow[j][0].z, pv[2], a); a = dfma(P.ow[j][0].w, pv[3], a);
+                a = dfma(P.ow[j][1].x, pv[4], a); a = dfma(P.ow[j][1].y, pv[5], a); a = dfma(P.ow[j][1].z, pv[6], a); a = dfma(P.ow[j][1].w, pv[7], a);
+                const float zqi = a + P.obv[j];
                 if (st < lim) acc[j] = acc[j] + zqi;
                 resr[j] = resr[j] - zqi;
-                res_s[tk][c0 + j] = resr[j];
+                res_s[c0 + j] = resr[j];
             }
         }
+    };
+    StageOps P0, P1;
+    if (nq > 0) fetch(P0, 0);
+    for (int st = 0; st < nq; st += 2) {
+        stage(P0, P1, st);
+        if (st + 1 < nq) stage(P1, P0, st + 1);
     }
-    if (live) {
 #pragma unroll
-        for (int j = 0; j < CO; ++j) zq[((size_t)bb * C + c0 + j) * T + tt] = acc[j];
-    }
+    for (int j = 0; j < CO; ++j) zq[((size_t)bb * C + c0 + j) * T + tt] = acc[j];
 }
 
 template <int CPT>
@@ -1135,8 +1132,7 @@ static hipError_t launch_dac_rvq_lat_t(const float* z, const float* in_w, const 
                                        const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
                                        const int32_t* nq_item, int B, int T, int nq, hipStream_t s, const float* cbn_pre, const float* cn2_pre)
 {
-    const int N = B * T;
-    hipLaunchKernelGGL((dac_rvq_lat_kernel<CPT, 8>), dim3((N + 1) / 2), dim3(256), 0, s,
+    hipLaunchKernelGGL((dac_rvq_lat_kernel<CPT, 4>), dim3((unsigned)(B * T)), dim3(256), 0, s,
                        z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, cbn_pre, cn2_pre);
     return hipGetLastError();
 }
@@ -1164,7 +1160,7 @@ hipError_t launch_dac_rvq(const float* z, const float* in_w, const float* in_b, 
 {
     if (B * T == 0) return hipSuccess;
     if (Dc != 8) return hipErrorInvalidValue;
-    // a handful of tokens (one segment is 75, the reference's batch of six 450): the latency form, two tokens per block
+    // a handful of tokens (one segment is 75, the reference's batch of six 450): the latency form, one token per block
     static const bool no_lat = [] { const bool o = getenv("MVQ_NO_DAC_RVQ_LAT") != nullptr; if (o) mvq::note_env_override(0x2000); return o; }();
     const bool aligned = ((reinterpret_cast<uintptr_t>(in_w) | reinterpret_cast<uintptr_t>(out_w) | reinterpret_cast<uintptr_t>(cb) |
                            reinterpret_cast<uintptr_t>(cbn_pre)) & 15) == 0;
