@@ -128,6 +128,7 @@ struct ConvArgs {
 #define MVQ_BF_ENV_ROWFAST 0x200
 #define MVQ_BF_ENV_NO_TOKEN_RVQ 0x400
 #define MVQ_BF_ENV_LAT_TILES 0x1000
+#define MVQ_BF_ENV_SMALL_TILES 0x8000
 constexpr unsigned conv_compile_flags()
 {
     unsigned f = 0;
@@ -1542,12 +1543,30 @@ inline bool conv_underfilled(const ConvArgs& a)
 {
     return (long)a.B * ((a.Ncols + 127) / 128) * ((a.Mrows + 127) / 128) < 160;
 }
+// 64 x 64 tiles instead of 128 x 128 (96): a question of how the grid divides over the 256 CUs.  Below 160 big tiles the launch
+// cannot put a block on most CUs at all.  Above it the big tiles run in ceil(big / 256) rounds of which the last may be nearly
+// empty -- at the reference's batch of six the 256-channel encoder level is 288 tiles (two rounds for 1.1 rounds of work: 84 of the
+// 157 TFLOP/s, profiles/r05_*B6*), the 768-channel decoder level 180 -- while four times as many quarter tiles fill their last
+// round, at ~0.85 of the big tile's per-block rate (less operand reuse).  The form with the better fill x rate wins, up to 600
+// big tiles; beyond that the big one always.  Measured at six segments (gpurun_out/g4): 11.60 -> 11.04 ms per step.
+// MVQ_SMALL_TILE_MAX=n replaces the rule by `big < n` (A/B runs).
 inline bool conv_prefer_small_tiles(const ConvArgs& a)
 {
     if (a.Mpad % 64 != 0) return false;
     if (a.vp_seg) return false;                       // virtually packed rows: the LDS-DMA 128-row tiles only
     const long big = (long)a.B * ((a.Ncols + 127) / 128) * ((a.Mrows + 127) / 128);
-    return big < 160;
+    static const long cap = [] {
+        const char* e = getenv("MVQ_SMALL_TILE_MAX");               // A/B knob (reported by mvq_build_flags)
+        if (e) note_env_override(MVQ_BF_ENV_SMALL_TILES);
+        return e ? atol(e) : -1L;
+    }();
+    if (cap >= 0) return big < cap;
+    if (big < 160) return true;
+    if (big >= 600) return false;                     // 2.3 rounds and up: the big tiles (and their split tail launch) fill well enough
+    const long small = 4 * big;
+    const double fill_big = (double)big / (double)((big + 255) / 256 * 256);
+    const double fill_small = (double)small / (double)((small + 255) / 256 * 256);
+    return 0.85 * fill_small > fill_big;
 }
 
 }  // namespace mvq
