@@ -69,6 +69,72 @@ __global__ __launch_bounds__(256) void layernorm_bwd_x_kernel(const float* __res
     if (cg == 0) { stats[2 * n] = mu; stats[2 * n + 1] = rstd; }
 }
 
+// The same arithmetic with the thread's channels held in registers (C = 16 * EPT): x and g are read ONCE -- every operand requested
+// before the first is used -- instead of four dependent passes over L2, and TOK = 4 tokens per block put a handful of tokens on four
+// times as many CUs.  profiles/r05_kernel_stats_B6_train_*: 67.8 us per call at the reference's batch of six (96 tokens per AR
+// chunk: six blocks, each thread 4 x 64 dependent L2 reads), 20 calls per training step.  Thread (tok, cg) still owns channels
+// cg, cg + 16, ... in ascending order and the 16 group partials are still added in group order: same bits as the kernel above.
+template <int TOK, int EPT>
+__global__ __launch_bounds__(TOK * LNB_CG) void layernorm_bwd_x_regs_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                       const float* __restrict__ gamma, const float* __restrict__ g,
+                                       float* __restrict__ gx, float* __restrict__ stats,
+                                       int B, int T, size_t sb, size_t sc, float eps)
+{
+    constexpr int C = LNB_CG * EPT;
+    __shared__ float red[LNB_CG * TOK];
+    const int tok = threadIdx.x & (TOK - 1), cg = threadIdx.x / TOK;
+    const int n = blockIdx.x * TOK + tok;
+    const bool live = n < B * T;
+    const int nc = live ? n : B * T - 1;           // a block's spare threads walk the LAST token (unconditional loads: a branch per
+    const int b = nc / T, t = nc - b * T;          // element made every load wait for the one before, 36 us per call) and store nothing
+    const size_t base = (size_t)b * sb + t;
+    const float* per = pe ? pe + (size_t)t * C : nullptr;
+    auto reduce = [&](float v) __attribute__((always_inline)) {
+        __syncthreads();
+        red[cg * TOK + tok] = v;
+        __syncthreads();
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LNB_CG; ++k) s += red[k * TOK + tok];
+        return s;
+    };
+    float xv[EPT], gg[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int c = cg + LNB_CG * j;
+        xv[j] = x[base + (size_t)c * sc];
+        gg[j] = g[base + (size_t)c * sc];
+    }
+    if (per) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) xv[j] += per[cg + LNB_CG * j];
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) gg[j] = gg[j] * gamma[cg + LNB_CG * j];
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) s += xv[j];
+    const float mu = reduce(s) / (float)C;
+    float var = 0.0f;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) { const float d = xv[j] - mu; var = dfma(d, d, var); }
+    const float rstd = 1.0f / __builtin_sqrtf(reduce(var) / (float)C + eps);
+    float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) { m1 += gg[j]; m2 = dfma(gg[j], (xv[j] - mu) * rstd, m2); }
+    m1 = reduce(m1) / (float)C;
+    m2 = reduce(m2) / (float)C;
+    if (!live) return;
+    if (gx) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const float xh = (xv[j] - mu) * rstd;
+            gx[base + (size_t)(cg + LNB_CG * j) * sc] = rstd * (gg[j] - m1 - xh * m2);
+        }
+    }
+    if (cg == 0) { stats[2 * n] = mu; stats[2 * n + 1] = rstd; }
+}
+
 __global__ __launch_bounds__(256) void layernorm_bwd_param_kernel(
     const float* __restrict__ x, const float* __restrict__ pe, const float* __restrict__ g,
     const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -100,7 +166,12 @@ hipError_t launch_layernorm_bwd(const float* x, const float* pe, const float* ga
 {
     const int n = B * T;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(layernorm_bwd_x_kernel, dim3((n + LNB_TOK - 1) / LNB_TOK), dim3(256), 0, s, x, pe, gamma, g, gx, stats, B, C, T, sb, sc, eps);
+    if (C == 1024 && n <= 1024)                      // the predictor / TokenNorm width, a few AR chunks of tokens: 4 tokens per block
+        hipLaunchKernelGGL((layernorm_bwd_x_regs_kernel<4, 64>), dim3((n + 3) / 4), dim3(4 * LNB_CG), 0, s, x, pe, gamma, g, gx, stats, B, T, sb, sc, eps);
+    else if (C == 1024)
+        hipLaunchKernelGGL((layernorm_bwd_x_regs_kernel<LNB_TOK, 64>), dim3((n + LNB_TOK - 1) / LNB_TOK), dim3(LNB_TOK * LNB_CG), 0, s, x, pe, gamma, g, gx, stats, B, T, sb, sc, eps);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_x_kernel, dim3((n + LNB_TOK - 1) / LNB_TOK), dim3(256), 0, s, x, pe, gamma, g, gx, stats, B, C, T, sb, sc, eps);
     hipLaunchKernelGGL(layernorm_bwd_param_kernel, dim3(C), dim3(256), 0, s, x, pe, g, stats, dgamma, dbeta, B, C, T, sb, sc);
     return hipGetLastError();
 }

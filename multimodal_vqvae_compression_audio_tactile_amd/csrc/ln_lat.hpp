@@ -53,36 +53,34 @@ __device__ __forceinline__ void ln_lat_task(const LnIo& io, int task, int B, int
     const bool worker = tid < 256;
     const int nn = task * TOK + tok;
     const bool live = worker && nn < B * n;
-    const int b = live ? nn / n : 0, i = live ? nn - b * n : 0;
+    const int nc = nn < B * n ? nn : B * n - 1;                      // spare lanes of the last task walk the LAST token and store nothing: every
+    const int b = nc / n, i = nc - b * n;                            // load below is unconditional (no branch per element between the requests)
     float* const row = tile + (size_t)tok * CP;
     __syncthreads();                                                 // the block's previous task is done with the tile
     float gm[EPT], bt[EPT];                                          // gamma / beta of the thread's first 16 channels: requested now, used last
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
-        const int c = cg + u * CGR;
-        const bool in = live && c < C;
-        gm[u] = in ? io.gamma[c] : 0.0f;
-        bt[u] = in ? io.beta[c] : 0.0f;
+        const int c = cg + u * CGR < C ? cg + u * CGR : C - 1;
+        gm[u] = io.gamma[c];
+        bt[u] = io.beta[c];
     }
     if (worker) {
         for (int c0 = cg; c0 < C; c0 += CGR * EPT) {
             float v[EPT], sv[EPT], pv[EPT];
 #pragma unroll
             for (int u = 0; u < EPT; ++u) {                          // all requests first
-                const int c = c0 + u * CGR;
-                const bool in = live && c < C;
+                const int c = c0 + u * CGR < C ? c0 + u * CGR : C - 1;
                 v[u] = 0.0f; sv[u] = 0.0f; pv[u] = 0.0f;
-                if (in) {
-                    if (io.x) v[u] = ld(io.x + (size_t)b * io.x_sb + (size_t)c * io.x_sc + i);
-                    else if (io.prev && i == 0) v[u] = ld(io.prev + (size_t)b * io.prev_sb + (size_t)c * io.prev_sc);
-                    if (io.sub) sv[u] = ld(io.sub + (size_t)b * io.sub_sb + (size_t)c * io.sub_sc + i);
-                    if (io.pe) pv[u] = io.pe[(size_t)i * C + c];
-                }
+                if (io.x) v[u] = ld(io.x + (size_t)b * io.x_sb + (size_t)c * io.x_sc + i);
+                else if (io.prev) v[u] = ld(io.prev + (size_t)b * io.prev_sb + (size_t)c * io.prev_sc);
+                if (io.sub) sv[u] = ld(io.sub + (size_t)b * io.sub_sb + (size_t)c * io.sub_sc + i);
+                if (io.pe) pv[u] = io.pe[(size_t)i * C + c];
             }
+            const bool shifted = !io.x;                              // the shift-by-one input: only token 0 of an item carries a value
 #pragma unroll
             for (int u = 0; u < EPT; ++u) {
                 const int c = c0 + u * CGR;
-                float e = v[u];
+                float e = (shifted && i != 0) ? 0.0f : v[u];
                 if (io.sub) e = e - sv[u];
                 if (io.pe) e = e + pv[u];
                 if (c < C) row[c] = live ? e : 0.0f;
