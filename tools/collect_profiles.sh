@@ -8,7 +8,8 @@ TAG=${1:-r04}
 COMMIT=${2:-unknown}
 OUT=gpurun_out/${TAG}prof
 mkdir -p "$OUT"
-BENCH_ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-latency"
+BENCH_ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-sweep"    # the trace is of the 256-segment steps only: the batch sweep launches the same
+                                                                                   # instantiations at 1-64 segments and would pull their per-kernel averages down
 
 echo "[1/8] kernel trace of the default bench"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ks" -- python3 bench.py $BENCH_ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/ks.err" || exit 11
@@ -48,6 +49,8 @@ cp "$(ls $OUT/ks_train/*/*kernel_stats.csv | tail -1)" "$OUT/kernel_stats_train_
 echo "[6/8] stored bench lines (after the traffic table: kernels_unchanged_since_profile must read true)"
 python3 bench.py --steps 5 --warmup 2 > "$OUT/bench_default_B256.json" 2> "$OUT/bench_default.err" || exit 61
 python3 bench.py --workload train --steps 5 --warmup 3 > "$OUT/bench_train_B256.json" 2> "$OUT/bench_train.err" || exit 62
+# the reference's own training batch (Training/compare_dacvsproposal_5.py:62), with its CPU baseline
+python3 bench.py --workload train --batch 6 --steps 10 --warmup 3 > "$OUT/bench_train_B6.json" 2> "$OUT/bench_train_B6.err" || exit 63
 
 echo "[7/8] latency + corpus"
 python3 tools/latency.py > "$OUT/latency_B1.json" 2> "$OUT/latency.err" || exit 71
