@@ -530,6 +530,8 @@ typedef struct mvq_ar_args {
 } mvq_ar_args;
 size_t mvq_ar_workspace_bytes(int batch, int t_lat);
 int mvq_ar_latents_f32(const mvq_ar_args* args, void* workspace, size_t workspace_bytes, void* stream);
+/* the same loop as stream-ordered stand-alone launches from one host call (batch <= 8; capturable; same bits) */
+int mvq_ar_latents_staged_f32(const mvq_ar_args* args, void* workspace, size_t workspace_bytes, void* stream);
 /* synchronises `stream`, then: MVQ_OK when every grid barrier of the last call on this workspace completed */
 int mvq_ar_check(const void* workspace, void* stream);
 

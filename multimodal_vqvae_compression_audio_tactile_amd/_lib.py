@@ -140,6 +140,7 @@ EXPORTS = {
     "mvq_decoder_bwd_input_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "mvq_ar_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mvq_ar_latents_f32": (c_int, [ctypes.POINTER(ArArgs), c_void_p, c_size_t, c_void_p]),
+    "mvq_ar_latents_staged_f32": (c_int, [ctypes.POINTER(ArArgs), c_void_p, c_size_t, c_void_p]),
     "mvq_ar_check": (c_int, [c_void_p, c_void_p]),
 }
 

@@ -24,12 +24,15 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "../../include/mvq.h"
+#include "conv_dispatch.hpp"
 #include "conv_lat.hpp"
+#include "kernels_small.hpp"
 #include "det_math.hpp"
 #include "ln_lat.hpp"
 
 namespace mvq {
 void set_last_error(const char* msg);
+hipError_t launch_layernorm_lat_io(const LnIo& io, int B, int C, int n, hipStream_t s);      // kernels_small.hip
 
 namespace {
 
@@ -410,14 +413,16 @@ size_t mvq_ar_workspace_bytes(int batch, int t_lat)
     return floats * sizeof(float) + 256 /* alignment */ + 256 /* barrier words */ + 8192 /* stage clocks */;
 }
 
-int mvq_ar_latents_f32(const mvq_ar_args* args, void* workspace, size_t workspace_bytes, void* stream)
+// argument checks + workspace carving shared by the two forms; returns MVQ_OK with `done` set when there is nothing to do
+static int ar_prepare(const mvq_ar_args* args, void* workspace, size_t workspace_bytes, mvq::ArKT& kt, bool& done)
 {
     using namespace mvq;
     auto fail = [](int code, const char* msg) { set_last_error(msg); return code; };
+    done = false;
     if (!args) return fail(MVQ_EINVAL, "ar_latents: null argument");
     const mvq_ar_args& a = *args;
     if (a.batch < 0 || a.t_lat < 0 || a.t_audio < 0 || a.books_use < 0) return fail(MVQ_EINVAL, "ar_latents: bad shape");
-    if (a.batch == 0 || a.t_lat == 0) return MVQ_OK;
+    if (a.batch == 0 || a.t_lat == 0) { done = true; return MVQ_OK; }
     if (a.c_lat != C_LAT || a.c_ff != C_FF || a.code_dim != D_CODE || a.heads != HEADS || a.chunk != CHUNK)
         return fail(MVQ_EUNSUPPORTED, "ar_latents: the fused loop covers the reference's shapes (c_lat 1024, FFN 2048, 8 heads, code dim 96, chunks of 16)");
     if (a.rvq_k <= 0 || a.rvq_k > 512) return fail(MVQ_EUNSUPPORTED, "ar_latents: K <= 512 codes per book");
@@ -430,7 +435,7 @@ int mvq_ar_latents_f32(const mvq_ar_args* args, void* workspace, size_t workspac
     if ((reinterpret_cast<uintptr_t>(a.books) & 15) != 0) return fail(MVQ_EINVAL, "ar_latents: books must be 16-byte aligned");
     if (conv_mpad(C_LAT) != C_LAT || conv_mpad(C_FF) != C_FF || conv_mpad(D_CODE) != D_CODE) return fail(MVQ_EUNSUPPORTED, "ar_latents: packed-row padding");
 
-    ArKT kt{};
+    kt = ArKT{};
     ArK& k = kt.k;
     k.a = a;
     char* p = reinterpret_cast<char*>(workspace);
@@ -444,6 +449,19 @@ int mvq_ar_latents_f32(const mvq_ar_args* args, void* workspace, size_t workspac
     k.q16 = take(C_LAT * f16); k.Q16 = take(C_LAT * f16); k.ctx16 = take(C_LAT * f16); k.hdn16 = take(C_LAT * f16); k.rN16 = take(C_LAT * f16);
     k.h16 = take((size_t)C_FF * f16); k.rD16 = take((size_t)D_CODE * f16); k.qD16 = take((size_t)D_CODE * f16);
     k.qT = take(C_LAT * fT); k.y1T = take(C_LAT * fT); k.zpT = take(C_LAT * fT);
+    fill_stages(kt.tab, k);
+    return MVQ_OK;
+}
+
+int mvq_ar_latents_f32(const mvq_ar_args* args, void* workspace, size_t workspace_bytes, void* stream)
+{
+    using namespace mvq;
+    auto fail = [](int code, const char* msg) { set_last_error(msg); return code; };
+    ArKT kt;
+    bool done = false;
+    if (const int rc = ar_prepare(args, workspace, workspace_bytes, kt, done); rc != MVQ_OK || done) return rc;
+    ArK& k = kt.k;
+    const mvq_ar_args& a = k.a;
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t lds_gemm = (size_t)(NTHR / 64) * 2 * LatCfg<1, 1, 1, 64>::BUF_FLOATS * sizeof(float);
@@ -465,7 +483,6 @@ int mvq_ar_latents_f32(const mvq_ar_args* args, void* workspace, size_t workspac
     k.nblocks = want < cus ? want : cus;
     if (k.nblocks < 1) k.nblocks = 1;
     if (hipMemsetAsync(k.bar, 0, k.ts ? 256 + 8192 : 256, st) != hipSuccess) return fail(MVQ_EHIP, "ar_latents: memset failed");
-    fill_stages(kt.tab, k);
     void* kargs[] = {&kt};
     const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(ar_loop_kernel), dim3((unsigned)k.nblocks), dim3(NTHR), kargs, (unsigned)lds, st);
     if (e != hipSuccess) {
@@ -473,6 +490,80 @@ int mvq_ar_latents_f32(const mvq_ar_args* args, void* workspace, size_t workspac
         snprintf(msg, sizeof(msg), "ar_latents: cooperative launch of %d blocks x %d threads, %zu B LDS: %s", k.nblocks, NTHR, lds, hipGetErrorString(e));
         return fail(MVQ_EHIP, msg);
     }
+    return MVQ_OK;
+}
+
+/* The same loop as ONE HOST CALL of stand-alone launches: the stage table of the persistent kernel above, each stage launched as the
+ * kernel it restates (conv1d_lat_kernel, layernorm_c_lat_kernel, attention_kernel, rvq_ema_forward_rows_kernel), stream-ordered,
+ * nothing allocated or synchronised (capturable).  Why it exists: at one segment the Python loop's ~85 foreign calls with their
+ * allocations cost as much host time as the kernels take on the device (eager encode 2.5 ms against 2.3 ms replayed as a graph);
+ * from C a launch costs 2-3 us.  Same kernels, same bits as the Python loop (tests/test_gpu_ar_fused.py).  Needs every GEMM in the
+ * latency form's range (batch <= 8: at most 1 024 16 x 16 tiles per launch). */
+int mvq_ar_latents_staged_f32(const mvq_ar_args* args, void* workspace, size_t workspace_bytes, void* stream)
+{
+    using namespace mvq;
+    auto fail = [](int code, const char* msg) { set_last_error(msg); return code; };
+    ArKT kt;
+    bool done = false;
+    if (const int rc = ar_prepare(args, workspace, workspace_bytes, kt, done); rc != MVQ_OK || done) return rc;
+    const ArK& k = kt.k;
+    const mvq_ar_args& a = k.a;
+    if (a.batch > 8) return fail(MVQ_EUNSUPPORTED, "ar_latents_staged: batch <= 8 (beyond it the LDS-tiled GEMMs of the per-stage loop win)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int B = a.batch, Tl = a.t_lat;
+    // chunk-local buffers start defined: a last chunk shorter than 16 tokens leaves columns nobody writes, and the search reads all 16
+    const size_t chunk_bytes = (size_t)(reinterpret_cast<char*>(k.qT) - reinterpret_cast<char*>(k.q16));
+    if (hipMemsetAsync(k.q16, 0, chunk_bytes, st) != hipSuccess) return fail(MVQ_EHIP, "ar_latents_staged: memset failed");
+    int32_t* const idx_tmp = reinterpret_cast<int32_t*>(k.ctx16);          // [books][B][16]: ctx16 is free between the attention and the next chunk
+    if ((size_t)a.books_use * B * CHUNK > (size_t)C_LAT * B * CHUNK) return fail(MVQ_EUNSUPPORTED, "ar_latents_staged: too many books");
+    hipError_t e = hipSuccess;
+    for (int s = 0; s < Tl && e == hipSuccess; s += CHUNK) {
+        const int n = Tl - s < CHUNK ? Tl - s : CHUNK;
+        for (int i = 0; i < N_STAGES && e == hipSuccess; ++i) {
+            const StageDesc& d = kt.tab[i];
+            switch (d.type) {
+                case ST_SKIP: break;
+                case ST_LN: {
+                    LnIo io = d.ln;
+                    if (io.x && (d.adv & ADV_LN_X)) io.x += s;
+                    if (d.adv & ADV_LN_PREV) io.prev = s > 0 ? io.prev + (s - 1) : nullptr;
+                    if (io.sub && (d.adv & ADV_LN_SUB)) io.sub += s;
+                    if (io.y1 && (d.adv & ADV_LN_Y1)) io.y1 += s;
+                    e = launch_layernorm_lat_io(io, B, C_LAT, n, st);
+                    break;
+                }
+                case ST_GEMM64: case ST_GEMM32: {
+                    ConvArgs c{};
+                    c.x = d.x + ((d.adv & ADV_X) ? s : 0); c.wp = d.wp; c.bias = d.bias;
+                    c.residual = d.res ? d.res + ((d.adv & ADV_RES) ? s : 0) : nullptr;
+                    c.y = d.y + ((d.adv & ADV_Y) ? s : 0);
+                    c.B = B; c.Cin = d.cin; c.Tin = CHUNK; c.Cout = d.cout; c.Tout = d.y_pitch; c.pad = 0;
+                    c.Mpad = d.cout; c.Mrows = d.cout; c.Ncols = n; c.act = d.act; c.up_s = 1;
+                    e = launch_conv_lat(c, 1, 1, 1, st);
+                    break;
+                }
+                case ST_ATTN: {
+                    const int ka = (a.t_audio < s + n ? a.t_audio : s + n) - (a.t_audio < s ? a.t_audio : s);
+                    e = launch_attention(k.Q16, a.k_all ? a.k_all + s : k.Q16, a.v_all ? a.v_all + s : k.Q16, k.ctx16, B, HEADS, DH, n, ka,
+                                         (size_t)C_LAT * CHUNK, CHUNK, (size_t)a.t_audio, (size_t)B * a.t_audio, st);
+                    break;
+                }
+                case ST_RVQ: {
+                    if (a.books_use > 0)
+                        e = launch_rvq_ema_forward(k.rD16, a.books, k.qD16, a.idx_out ? idx_tmp : nullptr, B, D_CODE, CHUNK, a.books_use, a.rvq_k, 1, st);
+                    else
+                        e = hipMemsetAsync(k.qD16, 0, (size_t)D_CODE * B * CHUNK * sizeof(float), st);
+                    if (e == hipSuccess && a.idx_out && a.books_use > 0)      // [books * B][16] -> idx_out[books * B][Tlat] at s (4-byte moves)
+                        e = launch_strided3d(reinterpret_cast<const float*>(idx_tmp), CHUNK, 0, nullptr, 0, 0,
+                                             reinterpret_cast<float*>(a.idx_out) + s, (size_t)Tl, 0, a.books_use * B, 1, n, st);
+                    if (e == hipSuccess && a.r_tokens)
+                        e = launch_strided3d(k.rD16, (size_t)D_CODE * CHUNK, CHUNK, nullptr, 0, 0, a.r_tokens + s, (size_t)D_CODE * Tl, (size_t)Tl, B, D_CODE, n, st);
+                    break;
+                }
+            }
+        }
+    }
+    if (e != hipSuccess) return fail(MVQ_EHIP, hipGetErrorString(e));
     return MVQ_OK;
 }
 

@@ -488,6 +488,14 @@ __global__ __launch_bounds__(256) void layernorm_c_lat_kernel(const LnIo io, int
     ln_lat_task(io, blockIdx.x, B, T, C, ln_lat_smem, threadIdx.x, [](const float* p) { return *p; });
 }
 
+hipError_t launch_layernorm_lat_io(const LnIo& io, int B, int C, int n, hipStream_t s)      // the general form (two outputs, shifted input): ar_fused.hip
+{
+    if (B * n == 0) return hipSuccess;
+    if (C % 64 != 0 || ln_lat_lds_floats(C) * sizeof(float) > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_c_lat_kernel, dim3((B * n + LN_LAT_TOK - 1) / LN_LAT_TOK), dim3(256), ln_lat_lds_floats(C) * sizeof(float), s, io, B, C, n);
+    return hipGetLastError();
+}
+
 __global__ void layernorm_c_kernel(const float* __restrict__ x, const float* __restrict__ pe,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ y, int B, int C, int T, size_t sb, size_t sc,

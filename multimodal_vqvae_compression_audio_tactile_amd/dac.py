@@ -36,7 +36,7 @@ DEC_RATES = (8, 5, 4, 2)
 # whole-stack C entry points (mvq_encoder_fwd_f32 / mvq_decoder_fwd_f32 / mvq_decoder_bwd_input_f32), whose plan is the library's.
 PLAN_ENV = ("MVQ_RU_PRESNAKED", "MVQ_VPACKED_LATENTS", "MVQ_PACKED_MIN_BATCH", "MVQ_PACKED_LATENTS", "MVQ_PY_PLAN")
 PLAN_OVERRIDES = {k: os.environ[k] for k in PLAN_ENV if k in os.environ}
-HOST_ENV_SEEN = {k: os.environ[k] for k in ("MVQ_TWO_STREAM_MAX_BATCH", "MVQ_AR_FUSED_MAX_BATCH") if k in os.environ}      # proposed.py: stream plan of the branches
+HOST_ENV_SEEN = {k: os.environ[k] for k in ("MVQ_TWO_STREAM_MAX_BATCH", "MVQ_AR_FUSED_MAX_BATCH", "MVQ_AR_STAGED_MAX_BATCH") if k in os.environ}      # proposed.py: stream plan of the branches
 USE_STACKS = not PLAN_OVERRIDES            # tests flip this to compare the two plans
 
 

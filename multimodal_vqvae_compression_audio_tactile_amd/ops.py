@@ -520,11 +520,14 @@ _AR_CHECKED = set()
 
 
 def ar_latents_fused(zt, z_run, *, k_all, v_all, t_audio, pe, ln_q, wq, wo, ln_f, w1, b1, w3, b3, ln_eps, tok, tok_eps, scale,
-                     wd, bd, wu, bu, books, books_use, heads, c_ff, code_dim, r_tokens=None, idx_out=None, tactile_only=False, chunk=16):
+                     wd, bd, wu, bu, books, books_use, heads, c_ff, code_dim, r_tokens=None, idx_out=None, tactile_only=False, chunk=16,
+                     staged=False):
     """The whole chunked AR loop as ONE persistent kernel (csrc/ar_fused.hip: mvq_ar_latents_f32): zt[B,C,Tlat] -> z_run[B,C,Tlat]
     (written in place), optionally r_tokens[B,96,Tlat] and idx_out[nb,B,Tlat] (int32).  ``k_all`` / ``v_all``: token-folded K / V
     of all chunks ([1,C,B*t_audio], CrossPredictor.keys_values) or None; the w* are K-major packed 1x1 weights (pack_conv1d);
-    ln_q / ln_f / tok = (weight, bias).  Same bits as the launch-per-stage path (tests/test_gpu_ar_fused.py)."""
+    ln_q / ln_f / tok = (weight, bias).  ``staged``: the same stages as stand-alone launches issued by ONE host call
+    (mvq_ar_latents_staged_f32; batch <= 8) instead of the persistent kernel.  Same bits as the Python loop either way
+    (tests/test_gpu_ar_fused.py)."""
     zt = _dev(zt, "zt")
     B, C, Tl = zt.shape
     nb_all, K = (books.shape[0], books.shape[1]) if books is not None else (0, 1)
@@ -541,6 +544,9 @@ def ar_latents_fused(zt, z_run, *, k_all, v_all, t_audio, pe, ln_q, wq, wo, ln_f
     L = _lib.lib()
     nbytes = L.mvq_ar_workspace_bytes(B, Tl)
     ws = torch.empty(max(nbytes, 4), device=zt.device, dtype=torch.uint8)
+    if staged:
+        check(L.mvq_ar_latents_staged_f32(ctypes.byref(a), ws.data_ptr(), nbytes, _stream()), "mvq_ar_latents_staged_f32")
+        return z_run
     check(L.mvq_ar_latents_f32(ctypes.byref(a), ws.data_ptr(), nbytes, _stream()), "mvq_ar_latents_f32")
     key = (B, Tl, zt.device.index, bool(tactile_only))
     if key not in _AR_CHECKED:            # co-residency of the persistent grid is a property of the shape: verified on its first use

@@ -228,9 +228,10 @@ class _ProposedBase(nn.Module):
             Ta = min(qa.shape[-1], Tlat)                                      # audio may be shorter (whole-file mode)
             if Ta > 0:                                                        # K, V of all chunks up front (3 launches)
                 kv_all = self.predict.keys_values(ops.fold_time_slice(qa, 0, Ta), B, AR_CHUNK_TOK)
-        if self._ar_fused_wanted(zt, books):
+        mode = self._ar_one_call_mode(zt, books)
+        if mode is not None:
             return self._ar_latents_fused(zt, z_run, r_tokens, kv_all, 0 if tactile_only else min(qa.shape[-1], Tlat), books, books_use,
-                                          tactile_only, want_indices)
+                                          tactile_only, want_indices, staged=(mode == "staged"))
         zt_prev, zp_n = None, -1      # the shift-by-one input: all zero except column 0 of each item (s > 0), so one zeroed
         for s in range(0, Tlat, AR_CHUNK_TOK):                               # buffer per chunk width serves every chunk
             e = min(Tlat, s + AR_CHUNK_TOK)
@@ -275,6 +276,25 @@ class _ProposedBase(nn.Module):
     # per-stage clocks can be read (MVQ_AR_TIMING=1), which is how the LayerNorm / GEMM-epilogue round trips of round 5 were found.
     AR_FUSED_MAX_BATCH = int(_dac.HOST_ENV_SEEN.get("MVQ_AR_FUSED_MAX_BATCH", "0"))
 
+    # The loop as ONE HOST CALL of the same stand-alone launches (mvq_ar_latents_staged_f32), for up to this many segments: at one
+    # segment the Python loop's ~85 foreign calls and their allocations cost as much host time as the kernels take on the device
+    # (eager encode 2.5 ms against 2.3 replayed as a graph).  Needs every GEMM in the latency form's range: 8 segments at most.
+    AR_STAGED_MAX_BATCH = min(8, int(_dac.HOST_ENV_SEEN.get("MVQ_AR_STAGED_MAX_BATCH", "8")))
+
+    def _ar_shapes_covered(self, zt, books):
+        p = self.predict
+        return (zt.is_cuda and zt.shape[0] > 0 and ops.get_arith() == "f32"
+                and zt.shape[1] == 1024 and p.h == 8 and p.ffn[1].out_features == 2048 and CODE_DIM == 96 and p.ln_q.eps == p.ffn[0].eps
+                and (books is None or (books.shape[1] <= 512 and books.shape[2] == CODE_DIM)))
+
+    def _ar_one_call_mode(self, zt, books):
+        """"fused" (opt-in persistent kernel), "staged" (one host call, stand-alone launches) or None (the Python loop)."""
+        if self._ar_fused_wanted(zt, books):
+            return "fused"
+        if zt.shape[0] <= self.AR_STAGED_MAX_BATCH and self._ar_shapes_covered(zt, books):
+            return "staged"
+        return None
+
     def _ar_fused_wanted(self, zt, books):
         p = self.predict
         return (zt.is_cuda and 0 < zt.shape[0] <= self.AR_FUSED_MAX_BATCH and ops.get_arith() == "f32"
@@ -282,7 +302,7 @@ class _ProposedBase(nn.Module):
                 and zt.shape[1] == 1024 and p.h == 8 and p.ffn[1].out_features == 2048 and CODE_DIM == 96 and p.ln_q.eps == p.ffn[0].eps
                 and (books is None or (books.shape[1] <= 512 and books.shape[2] == CODE_DIM)))
 
-    def _ar_latents_fused(self, zt, z_run, r_tokens, kv_all, t_audio, books, books_use, tactile_only, want_indices):
+    def _ar_latents_fused(self, zt, z_run, r_tokens, kv_all, t_audio, books, books_use, tactile_only, want_indices, staged=False):
         B, _, Tlat = zt.shape
         p, L, ln = self.predict, self.predict._lin, self.tokennorm.ln
         nb = 0 if books is None else (books.shape[0] if books_use is None else max(0, min(int(books_use), books.shape[0])))
@@ -295,7 +315,7 @@ class _ProposedBase(nn.Module):
             w3=L["f3"].wp(), b3=det(p.ffn[3].bias), ln_eps=p.ln_q.eps, tok=(det(ln.weight), det(ln.bias)), tok_eps=ln.eps,
             scale=self._scale_value(), wd=self._pd.wp(), bd=det(self.proj_down.bias), wu=self._pu.wp(), bu=det(self.proj_up.bias),
             books=books, books_use=books_use, heads=p.h, c_ff=p.ffn[1].out_features, code_dim=CODE_DIM, r_tokens=r_tokens, idx_out=idx,
-            tactile_only=tactile_only, chunk=AR_CHUNK_TOK)
+            tactile_only=tactile_only, chunk=AR_CHUNK_TOK, staged=staged)
         if want_indices:
             return z_run, r_tokens, idx.long()
         return z_run, r_tokens

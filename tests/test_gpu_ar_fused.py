@@ -26,45 +26,50 @@ def _latents(B, Tlat, Ta, seed, dev):
     return qa.to(dev), zt.to(dev)
 
 
-def _both(net, qa, zt, **kw):
-    keep = net.AR_FUSED_MAX_BATCH
+def _both(net, qa, zt, form="fused", **kw):
+    """(one-call form, Python loop) of the same call.  form: "fused" = the persistent kernel (an opt-in), "staged" = one host call of
+    stand-alone launches (the default up to 8 segments)."""
+    keep = net.AR_FUSED_MAX_BATCH, net.AR_STAGED_MAX_BATCH
     try:
-        net.AR_FUSED_MAX_BATCH = 8                         # the fused loop is an opt-in (proposed.py: AR_FUSED_MAX_BATCH)
-        assert net._ar_fused_wanted(zt, net.vq.stacked())
-        fused = net._ar_latents(qa, zt, **kw)
-        net.AR_FUSED_MAX_BATCH = 0
-        assert not net._ar_fused_wanted(zt, net.vq.stacked())
+        net.AR_FUSED_MAX_BATCH, net.AR_STAGED_MAX_BATCH = (8, 0) if form == "fused" else (0, 8)
+        assert net._ar_one_call_mode(zt, net.vq.stacked()) == form
+        one = net._ar_latents(qa, zt, **kw)
+        net.AR_FUSED_MAX_BATCH, net.AR_STAGED_MAX_BATCH = 0, 0
+        assert net._ar_one_call_mode(zt, net.vq.stacked()) is None
         plain = net._ar_latents(qa, zt, **kw)
     finally:
-        net.AR_FUSED_MAX_BATCH = keep
-    return fused, plain
+        net.AR_FUSED_MAX_BATCH, net.AR_STAGED_MAX_BATCH = keep
+    return one, plain
 
 
-@pytest.mark.parametrize("B,Tlat,Ta", [(1, 75, 75), (6, 75, 75), (2, 35, 20), (3, 16, 16), (1, 5, 5), (2, 33, 40), (2, 20, 0)])
-def test_fused_loop_equals_launch_per_stage(B, Tlat, Ta, nets, dev):
+@pytest.mark.parametrize("form", ["fused", "staged"])
+@pytest.mark.parametrize("B,Tlat,Ta", [(1, 75, 75), (6, 75, 75), (2, 35, 20), (3, 16, 16), (1, 5, 5), (2, 33, 40), (2, 20, 0), (8, 40, 40)])
+def test_fused_loop_equals_launch_per_stage(B, Tlat, Ta, form, nets, dev):
     net = nets[(8, 512)]
     qa, zt = _latents(B, Tlat, Ta, 100 + B + Tlat, dev)
-    fused, plain = _both(net, qa, zt, want_tokens=True, want_indices=True)
+    fused, plain = _both(net, qa, zt, form, want_tokens=True, want_indices=True)
     for f, p, name in zip(fused, plain, ("z_run", "r_tokens", "indices")):
         assert f.shape == p.shape and f.dtype == p.dtype, name
         assert torch.equal(f, p), f"{name}: {int((f != p).sum())} of {f.numel()} elements differ"
     assert bool(torch.isfinite(fused[0]).all())
 
 
+@pytest.mark.parametrize("form", ["fused", "staged"])
 @pytest.mark.parametrize("books,K,use", [(8, 512, 3), (8, 512, 0), (3, 128, None), (3, 128, 2)])
-def test_fused_loop_book_counts_and_sizes(books, K, use, nets, dev):
+def test_fused_loop_book_counts_and_sizes(books, K, use, form, nets, dev):
     net = nets[(books, K)]
     qa, zt = _latents(2, 40, 40, 7, dev)
-    fused, plain = _both(net, qa, zt, books_use=use, want_indices=True)
+    fused, plain = _both(net, qa, zt, form, books_use=use, want_indices=True)
     assert torch.equal(fused[0], plain[0])
     assert fused[1] is None and plain[1] is None
     assert torch.equal(fused[2], plain[2]) and fused[2].shape[0] == (books if use is None else use)
 
 
-def test_fused_loop_tactile_only(nets, dev):
+@pytest.mark.parametrize("form", ["fused", "staged"])
+def test_fused_loop_tactile_only(form, nets, dev):
     net = nets[(8, 512)]
     _, zt = _latents(4, 75, 1, 9, dev)
-    fused, plain = _both(net, None, zt, tactile_only=True, want_tokens=True)
+    fused, plain = _both(net, None, zt, form, tactile_only=True, want_tokens=True)
     assert torch.equal(fused[0], plain[0]) and torch.equal(fused[1], plain[1])
 
 
@@ -86,13 +91,14 @@ def test_fused_loop_selection(nets, dev, monkeypatch):
     books = net.vq.stacked()
     _, zt = _latents(1, 16, 1, 3, dev)
     assert not net._ar_fused_wanted(zt, books)                 # off by default: measured slower than the per-stage launches
+    assert net._ar_one_call_mode(zt, books) == "staged"        # the default at small batches: one host call, the same launches
     monkeypatch.setattr(net, "AR_FUSED_MAX_BATCH", 8)
     assert net._ar_fused_wanted(zt, books)
     big = torch.empty(net.AR_FUSED_MAX_BATCH + 1, 1024, 16, device=dev)
-    assert not net._ar_fused_wanted(big, books)
+    assert not net._ar_fused_wanted(big, books) and net._ar_one_call_mode(big, books) is None
     with ops.arith("bf16x6"):                                  # the opt-in modes keep their own kernels
-        assert not net._ar_fused_wanted(zt, books)
-    g = torch.cuda.CUDAGraph()                                 # a cooperative launch cannot be captured: capture takes the per-stage path
+        assert net._ar_one_call_mode(zt, books) is None
+    g = torch.cuda.CUDAGraph()                                 # a cooperative launch cannot be captured: capture takes the staged form
     qa, zt = _latents(1, 32, 32, 5, dev)
     want = net._ar_latents(qa, zt)[0]
     s = torch.cuda.Stream()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the AR loop alone: the persistent kernel (csrc/ar_fused.hip) against the launch-per-stage loop, by batch size.
+"""A/B of the AR loop alone: the persistent kernel (csrc/ar_fused.hip), the same stages as one host call of stand-alone launches
+(mvq_ar_latents_staged_f32) and the Python loop, by batch size.
    usage (GPU box): python3 tools/ar_fused_ab.py [B ...]   -> one JSON line per batch size (ms per call, HIP events, 20 calls)"""
 import json
 import sys
@@ -33,13 +34,14 @@ def main():
         zt = (torch.randn(B, 1024, 75, generator=g) * 0.7).to(dev)
         qa = (torch.randn(B, 1024, 75, generator=g) * 0.7).to(dev)
         row = {"batch": B}
-        for name, cap in (("fused_ms", 1 << 20), ("per_stage_ms", 0)):
-            net.AR_FUSED_MAX_BATCH = cap
+        outs = {}
+        for name, fused_cap, staged_cap in (("fused_ms", 1 << 20, 0), ("staged_one_host_call_ms", 0, 8), ("python_loop_ms", 0, 0)):
+            if name.startswith("staged") and B > 8:
+                continue
+            net.AR_FUSED_MAX_BATCH, net.AR_STAGED_MAX_BATCH = fused_cap, staged_cap
             row[name] = round(timed(lambda: net._ar_latents(qa, zt)), 4)
-        net.AR_FUSED_MAX_BATCH = 1 << 20
-        a = net._ar_latents(qa, zt)[0]
-        net.AR_FUSED_MAX_BATCH = 0
-        row["bit_equal"] = bool(torch.equal(a, net._ar_latents(qa, zt)[0]))
+            outs[name] = net._ar_latents(qa, zt)[0]
+        row["bit_equal"] = all(bool(torch.equal(v, outs["python_loop_ms"])) for v in outs.values())
         print(json.dumps(row), flush=True)
 
 
