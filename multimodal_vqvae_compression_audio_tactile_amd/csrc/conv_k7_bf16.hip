@@ -99,12 +99,12 @@ __device__ __host__ __forceinline__ int f16_scale_exp(unsigned amax_bits)
 {
     const int e = (int)((amax_bits >> 23) & 0xff);                 // biased exponent of the maximum (sign bit is clear)
     if (e == 0 || e == 0xff) return 0;                              // zero / denormal / non-finite maximum: no scaling
-    return 13 - (e - 127);                                          // S = 2^this
-}
-__device__ __forceinline__ float f16_pow2(int k)
+    const int k = 13 - (e - 127);                                   // S = 2^k
+    return k < -126 ? -126 : (k > 126 ? 126 : k);                   // clamped ONCE, so that 2^k and 2^-k are both normal floats and the
+}                                                                   // epilogue undoes exactly the scale the split applied (a maximum below
+__device__ __forceinline__ float f16_pow2(int k)                    // 2^-113 keeps fewer significant bits, never a factor of two)
 {
-    k = k < -126 ? -126 : (k > 127 ? 127 : k);
-    return __uint_as_float((unsigned)(k + 127) << 23);
+    return __uint_as_float((unsigned)(k + 127) << 23);              // k in [-126, 126] (f16_scale_exp)
 }
 __device__ __forceinline__ float f16_scale(unsigned amax_bits) { return f16_pow2(f16_scale_exp(amax_bits)); }
 __device__ __forceinline__ float f16_inv_scale(unsigned amax_bits) { return f16_pow2(-f16_scale_exp(amax_bits)); }

@@ -138,6 +138,25 @@ def test_conv_k7_f16x3_is_fp32_class(C, T, dil, tvalid, gain, dev):
         assert e_new.max().item() <= 8.0 * e_old.max().item() + 1e-12, (b, e_new.max().item(), e_old.max().item())
 
 
+def test_conv_k7_f16x3_scale_and_inverse_agree_at_tiny_magnitudes(dev):
+    """An item whose maximum is ~2^-120 (a vanishing gradient in the dgrad use): the scale exponent is clamped ONCE, so the epilogue
+    undoes exactly the scale the split applied -- the output is the scaled output of the same item at magnitude 1, not twice it."""
+    from multimodal_vqvae_compression_audio_tactile_amd import ops
+    torch.manual_seed(5)
+    B, C, T, dil = 2, 128, 128, 1
+    x = torch.randn(B, C, T, device=dev)
+    tiny = 2.0 ** -120
+    x2 = x.clone(); x2[1] *= tiny                                                 # exact: a power of two
+    w = torch.randn(C, C, 7, device=dev) / math.sqrt(7 * C)
+    wq, wamax = ops.pack_conv1d_k7_f16x2(w)
+    y = ops.conv1d_k7_f16x3(*ops.f16x2_split(x), wq, wamax, B, C, T, C, dil)
+    y2 = ops.conv1d_k7_f16x3(*ops.f16x2_split(x2), wq, wamax, B, C, T, C, dil)
+    assert torch.equal(y2[0], y[0])
+    ratio = (y2[1].double() / tiny) / y[1].double()
+    big = y[1].abs() > 0.1 * y[1].abs().max()
+    assert (ratio[big] - 1.0).abs().max().item() < 1e-3, ratio[big].min().item()   # was 2.0 before the single clamp
+
+
 def test_conv_k7_bf16x6_rejects_bad_shapes(dev):
     from multimodal_vqvae_compression_audio_tactile_amd import ops
     from multimodal_vqvae_compression_audio_tactile_amd._lib import MvqError
