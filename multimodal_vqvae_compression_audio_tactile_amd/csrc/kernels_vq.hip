@@ -10,6 +10,7 @@
 //      normalisation, cosine search against the LDS-resident normalised codebook, straight-through out_proj
 //      and residual update, all stages for a block's 16 tokens with the residual held in registers.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -970,21 +971,22 @@ hipError_t launch_dac_rvq_prepare(const float* cb, float* cbn, float* cn2, int n
 }
 
 // ------------------------------------------------------------------------------------------------
-// Latency form of the DAC quantiser (round 5): ONE TOKEN PER BLOCK, 256 threads, nothing staged in LDS, and every operand of stage
-// s + 1 requested at the top of stage s.
+// Latency form of the DAC quantiser (round 5): TOKB tokens per block of 256 threads (launched with ONE), nothing staged in LDS,
+// every operand of stage s + 1 requested at the top of stage s and held in registers.
 // profiles/r05_kernel_stats_B1_encode_before.csv: dac_rvq_kernel takes 598 us for the 75 tokens of one segment -- 19 us per stage on
 // 5 of the 256 CUs: a block copies ~100 KB of stage weights and codebook into LDS per stage, and a thread then walks 8 in_proj
 // chains of 64, 64 codes and 64 out_proj channels one after another.  The contract fixes the CHAINS (in_proj: 16 block partials of
 // C/16 channels per codebook dimension, added in block order; out_proj: an 8-long chain per channel; scores: an 8-long chain per
-// code), not who runs them: here the token's first 128 threads take ONE partial chain each, and every thread K/256 codes and C/256
-// channels, straight from global memory (L2-resident: every block reads the same 136 KB per stage).
-// The first cut (two tokens per block, rows requested one PHASE ahead) still took 8.2 us per stage (gpurun_out/r05bsmall,
-// profiles/r05_kernel_stats_B1_encode_mid.csv: 262 us): a phase is ~0.2 us of arithmetic, an L2 round trip several times that, so
-// every phase still began by waiting.  With one token per block a thread's share of a stage is 42 sixteen-byte rows (168 VGPRs);
-// a block per CU has 512 VGPRs per lane, so TWO stages fit and the next stage's rows travel during the whole current stage.
-// Needs the prepared codebook (mvq_dac_rvq_prepare_f32).  LDS: res[C] | part[16][8] | ze[8] | pre[8] | red
+// code), not who runs them: here threads 0..127 take ONE partial chain each, and every thread K/256 codes and C/256 channels.
+// Cuts measured, all bit-equal: two tokens per block with rows requested a PHASE ahead, 262 us (a phase is ~0.2 us of arithmetic, a
+// round trip to L2 several times that); one token per block with a whole STAGE in flight, 210-240 us (a thread's share of a stage
+// is 42 sixteen-byte rows = 168 VGPRs; a block per CU has 512 per lane, so two stages fit); four tokens per block, 396 us (see the
+// launcher).  Clocks read inside the one-token form: of a stage's 6.5 us, 3.4 go by while the 49 loads of the next stage are
+// ISSUED (the CU's vector-memory path delivers 64 B/clk and a block pulls 170 KB per stage through it) -- the stage is bound by that
+// path and by the 8-cycle dependent issue of a wave that is alone on its SIMD.
+// Needs the prepared codebook (mvq_dac_rvq_prepare_f32).  LDS: res[TOKB][C] | part[TOKB][16][8] | ze | pre | red
 // ------------------------------------------------------------------------------------------------
-template <int CPT, int KJ>    // C = 16 * CPT channels, K = 256 * KJ codes, Dc = 8
+template <int CPT, int KJ, int TOKB>    // C = 16 * CPT channels, K = 256 * KJ codes, Dc = 8, TOKB tokens per block
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dac_rvq_lat_kernel(
     const float* __restrict__ z, const float* __restrict__ in_w, const float* __restrict__ in_b,
     const float* __restrict__ cb, const float* __restrict__ out_w, const float* __restrict__ out_b,
@@ -994,25 +996,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 {
     constexpr int C = 16 * CPT, Dc = 8, K = 256 * KJ, CO = C / 256, IV = CPT / 4;
     static_assert(C % 256 == 0 && CPT % 4 == 0, "a thread owns C / 256 channels; in_proj pieces are 16-byte rows");
+    static_assert(TOKB * Dc <= 64, "one wave sums the block partials of every token");
     typedef float v4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) float res_s[C];
-    __shared__ float part[16][Dc], ze[Dc], pre[Dc], red_s[4];
-    __shared__ int red_i[4];
+    __shared__ __attribute__((aligned(16))) float res_s[TOKB][C];
+    __shared__ float part[TOKB][16][Dc], ze[TOKB][Dc], pre[TOKB][Dc], red_s[TOKB][4];
+    __shared__ int red_i[TOKB][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n = blockIdx.x;                                      // grid = B * T tokens
-    const int bb = n / T, tt = n - bb * T;
-    const int lim = nq_item ? nq_item[bb] : nq;
+    const int N = B * T;
+    int bbv[TOKB], ttv[TOKB], limv[TOKB];
+    bool livev[TOKB];
+#pragma unroll
+    for (int k = 0; k < TOKB; ++k) {                               // a block's spare tokens repeat the LAST token and store nothing
+        const int n = blockIdx.x * TOKB + k;
+        livev[k] = n < N;
+        const int nc = livev[k] ? n : N - 1;
+        bbv[k] = nc / T; ttv[k] = nc - bbv[k] * T;
+        limv[k] = nq_item ? nq_item[bbv[k]] : nq;
+    }
     const int g = tid >> 3, d_in = tid & 7;                        // in_proj role (threads 0..127): block partial g of codebook dimension d_in
     const bool inproj = tid < 128;
-    const int c0 = tid * CO;                                       // out_proj role: channels c0 .. c0 + CO - 1
+    const int c0 = tid * CO;                                       // out_proj role: channels c0 .. c0 + CO - 1 of every token
 
-    float resr[CO], acc[CO];
+    float resr[TOKB][CO], acc[TOKB][CO];
 #pragma unroll
-    for (int j = 0; j < CO; ++j) {
-        acc[j] = 0.0f;
-        resr[j] = z[((size_t)bb * C + c0 + j) * T + tt];
-        res_s[c0 + j] = resr[j];
-    }
+    for (int k = 0; k < TOKB; ++k)
+#pragma unroll
+        for (int j = 0; j < CO; ++j) {
+            acc[k][j] = 0.0f;
+            resr[k][j] = z[((size_t)bbv[k] * C + c0 + j) * T + ttv[k]];
+            res_s[k][c0 + j] = resr[k][j];
+        }
     struct StageOps {
         v4 iw[IV];                                                 // in_proj row piece of (stage, d_in, block g): CPT floats
         v4 sw[KJ][2], rw[KJ][2];                                   // codes k = tid + 256 j: normalised row (search), raw row (straight-through value)
@@ -1020,8 +1033,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float cn2v[KJ], obv[CO], inb;
     };
     auto fetch = [&](StageOps& P, int st) __attribute__((always_inline)) {
-        if (inproj) {
-            const float* wr = in_w + ((size_t)st * Dc + d_in) * C + g * CPT;
+        {   // every thread requests a row piece (threads 128..255 the piece of thread - 128, unused): a load under a divergent branch
+            // would make every later wait for P cover Pn's loads as well, i.e. undo the prefetch
+            const float* wr = in_w + ((size_t)st * Dc + d_in) * C + (g & 15) * CPT;
 #pragma unroll
             for (int u = 0; u < IV; ++u) P.iw[u] = *reinterpret_cast<const v4*>(wr + 4 * u);
         }
@@ -1038,42 +1052,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             P.ow[j][0] = *reinterpret_cast<const v4*>(wr); P.ow[j][1] = *reinterpret_cast<const v4*>(wr + 4);
             P.obv[j] = out_b[(size_t)st * C + c0 + j];
         }
-        P.inb = tid < Dc ? in_b[(size_t)st * Dc + tid] : 0.0f;
+        P.inb = in_b[(size_t)st * Dc + (tid & (Dc - 1))];
     };
     auto stage = [&](const StageOps& P, StageOps& Pn, int st) __attribute__((always_inline)) {
-        if (st + 1 < nq) fetch(Pn, st + 1);                        // in flight for this whole stage
+        fetch(Pn, st + 1 < nq ? st + 1 : st);                      // in flight for this whole stage.  UNCONDITIONAL (the last stage requests its
+                                                                   // own rows again): behind a branch the wait for P would have to cover Pn's loads too
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                                           // res_s holds this stage's residual
-        if (inproj) {   // in_proj block partial: channels g*CPT .. +CPT-1 ascending, from +0
-            const float* rr = &res_s[g * CPT];
-            float p = 0.0f;
+        __syncthreads();                                           // res_s holds this stage's residuals
+        if (inproj) {   // in_proj block partial: channels g*CPT .. +CPT-1 ascending, from +0 -- one chain per token, interleaved
+            float p[TOKB];
+#pragma unroll
+            for (int k = 0; k < TOKB; ++k) p[k] = 0.0f;
 #pragma unroll
             for (int u = 0; u < IV; ++u) {
-                const v4 r4 = *reinterpret_cast<const v4*>(rr + 4 * u);
-                p = dfma(P.iw[u].x, r4.x, p); p = dfma(P.iw[u].y, r4.y, p); p = dfma(P.iw[u].z, r4.z, p); p = dfma(P.iw[u].w, r4.w, p);
-            }
-            part[g][d_in] = p;
-        }
-        __syncthreads();
-        if (tid < Dc) {                                            // the 16 block partials in block order, + bias
-            float a = part[0][tid];
 #pragma unroll
-            for (int gg = 1; gg < 16; ++gg) a = a + part[gg][tid];
-            const float v = a + P.inb;
-            ze[tid] = v;
-            latents[((size_t)bb * nq * Dc + (size_t)st * Dc + tid) * T + tt] = v;
+                for (int k = 0; k < TOKB; ++k) {
+                    const v4 r4 = *reinterpret_cast<const v4*>(&res_s[k][g * CPT + 4 * u]);
+                    p[k] = dfma(P.iw[u].x, r4.x, p[k]); p[k] = dfma(P.iw[u].y, r4.y, p[k]); p[k] = dfma(P.iw[u].z, r4.z, p[k]); p[k] = dfma(P.iw[u].w, r4.w, p[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < TOKB; ++k) part[k][g][d_in] = p[k];
         }
         __syncthreads();
-        float bs = -__builtin_inff(); int bi = 0x7fffffff;
-        v4 br0 = P.rw[0][0], br1 = P.rw[0][1];                     // raw row of this thread's best code so far (the winner publishes its own)
-        {   // F.normalize over Dc (every thread computes the same values), then this thread's codes, ascending
+        if (tid < TOKB * Dc) {                                     // the 16 block partials in block order, + bias: thread (token, dimension)
+            const int k = tid >> 3, d = tid & 7;
+            float a = part[k][0][d];
+#pragma unroll
+            for (int gg = 1; gg < 16; ++gg) a = a + part[k][gg][d];
+            const float v = a + P.inb;                             // inb was fetched for dimension tid & 7
+            ze[k][d] = v;
+            const int n = blockIdx.x * TOKB + k;                   // (k is a run-time index here: recompute the token's coordinates)
+            if (n < N) latents[((size_t)(n / T) * nq * Dc + (size_t)st * Dc + d) * T + (n - (n / T) * T)] = v;
+        }
+        __syncthreads();
+        float bs[TOKB]; int bi[TOKB];
+        v4 br0[TOKB], br1[TOKB];                                   // raw row of this thread's best code so far, per token (a winner publishes its own)
+#pragma unroll
+        for (int k = 0; k < TOKB; ++k) {   // F.normalize over Dc (every thread computes the same values), then this thread's codes, ascending
+            bs[k] = -__builtin_inff(); bi[k] = 0x7fffffff; br0[k] = P.rw[0][0]; br1[k] = P.rw[0][1];
             float ss = 0.0f;
 #pragma unroll
-            for (int d = 0; d < Dc; ++d) { const float v = ze[d]; ss = dfma(v, v, ss); }
+            for (int d = 0; d < Dc; ++d) { const float v = ze[k][d]; ss = dfma(v, v, ss); }
             const float den = __builtin_fmaxf(__builtin_sqrtf(ss), 1e-12f);
             float s2 = 0.0f, ev[Dc];
 #pragma unroll
-            for (int d = 0; d < Dc; ++d) { ev[d] = ze[d] / den; s2 = dfma(ev[d], ev[d], s2); }
+            for (int d = 0; d < Dc; ++d) { ev[d] = ze[k][d] / den; s2 = dfma(ev[d], ev[d], s2); }
 #pragma unroll
             for (int j = 0; j < KJ; ++j) {
                 float dot = 0.0f;
@@ -1081,39 +1105,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 dot = dfma(ev[4], P.sw[j][1].x, dot); dot = dfma(ev[5], P.sw[j][1].y, dot); dot = dfma(ev[6], P.sw[j][1].z, dot); dot = dfma(ev[7], P.sw[j][1].w, dot);
                 const float dist = (s2 - 2.0f * dot) + P.cn2v[j];
                 const float sc = -dist;
-                if (sc > bs) { bs = sc; bi = tid + 256 * j; br0 = P.rw[j][0]; br1 = P.rw[j][1]; }
+                if (sc > bs[k]) { bs[k] = sc; bi[k] = tid + 256 * j; br0[k] = P.rw[j][0]; br1[k] = P.rw[j][1]; }
             }
         }
-        wave_argmax(bs, bi);
-        if (lane == 0) { red_s[wv] = bs; red_i[wv] = bi; }
-        __syncthreads();
-        {
-            float cs = red_s[0]; int id = red_i[0];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) amax_combine(cs, id, red_s[w], red_i[w]);
+        for (int k = 0; k < TOKB; ++k) {
+            float s_ = bs[k]; int i_ = bi[k];
+            wave_argmax(s_, i_);
+            if (lane == 0) { red_s[k][wv] = s_; red_i[k][wv] = i_; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TOKB; ++k) {
+            float cs = red_s[k][0]; int id = red_i[k][0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) amax_combine(cs, id, red_s[k][w], red_i[k][w]);
             if (id < 0 || id >= K) id = 0;
             if (tid == (id & 255)) {                               // the thread that holds the winning code: its own best IS the winner
-                const v4 r0 = br0, r1 = br1;
+                const v4 r0 = br0[k], r1 = br1[k];
                 const float raw[Dc] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-                for (int d = 0; d < Dc; ++d) { const float zv = ze[d]; pre[d] = zv + (raw[d] - zv); }
-                codes[((size_t)bb * nq + st) * T + tt] = id;
+                for (int d = 0; d < Dc; ++d) { const float zv = ze[k][d]; pre[k][d] = zv + (raw[d] - zv); }
+                if (livev[k]) codes[((size_t)bbv[k] * nq + st) * T + ttv[k]] = id;
             }
         }
         __syncthreads();
-        {   // out_proj: an 8-long chain per owned channel, + bias; accumulate (under the item's stage limit) and update the residual
+#pragma unroll
+        for (int k = 0; k < TOKB; ++k) {   // out_proj: an 8-long chain per owned channel, + bias; accumulate (under the item's stage limit), update the residual
             float pv[Dc];
 #pragma unroll
-            for (int d = 0; d < Dc; ++d) pv[d] = pre[d];
+            for (int d = 0; d < Dc; ++d) pv[d] = pre[k][d];
 #pragma unroll
             for (int j = 0; j < CO; ++j) {
                 float a = 0.0f;
                 a = dfma(P.ow[j][0].x, pv[0], a); a = dfma(P.ow[j][0].y, pv[1], a); a = dfma(P.ow[j][0].z, pv[2], a); a = dfma(P.ow[j][0].w, pv[3], a);
                 a = dfma(P.ow[j][1].x, pv[4], a); a = dfma(P.ow[j][1].y, pv[5], a); a = dfma(P.ow[j][1].z, pv[6], a); a = dfma(P.ow[j][1].w, pv[7], a);
                 const float zqi = a + P.obv[j];
-                if (st < lim) acc[j] = acc[j] + zqi;
-                resr[j] = resr[j] - zqi;
-                res_s[c0 + j] = resr[j];
+                if (st < limv[k]) acc[k][j] = acc[k][j] + zqi;
+                resr[k][j] = resr[k][j] - zqi;
+                res_s[k][c0 + j] = resr[k][j];
             }
         }
     };
@@ -1124,7 +1154,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (st + 1 < nq) stage(P1, P0, st + 1);
     }
 #pragma unroll
-    for (int j = 0; j < CO; ++j) zq[((size_t)bb * C + c0 + j) * T + tt] = acc[j];
+    for (int k = 0; k < TOKB; ++k)
+        if (livev[k]) {
+#pragma unroll
+            for (int j = 0; j < CO; ++j) zq[((size_t)bbv[k] * C + c0 + j) * T + ttv[k]] = acc[k][j];
+        }
 }
 
 template <int CPT>
@@ -1132,7 +1166,12 @@ static hipError_t launch_dac_rvq_lat_t(const float* z, const float* in_w, const 
                                        const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
                                        const int32_t* nq_item, int B, int T, int nq, hipStream_t s, const float* cbn_pre, const float* cn2_pre)
 {
-    hipLaunchKernelGGL((dac_rvq_lat_kernel<CPT, 4>), dim3((unsigned)(B * T)), dim3(256), 0, s,
+    // tokens per block: ONE.  Four (the kernel is written for any TOKB) share a stage's 104 KB among four tokens and interleave their
+    // chains, but a stage then takes 12.4 us instead of 6.5 and a quarter as many CUs work: 396 against 240 us for the 75 tokens of
+    // one segment, about equal at 450 tokens (gpurun_out/h8).  What a stage costs is its ~3 000 dependent-issue instructions per
+    // token on a wave that is alone on its SIMD, not the bytes.
+    constexpr int TOKB = 1;
+    hipLaunchKernelGGL((dac_rvq_lat_kernel<CPT, 4, TOKB>), dim3((unsigned)((B * T + TOKB - 1) / TOKB)), dim3(256), 0, s,
                        z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, cbn_pre, cn2_pre);
     return hipGetLastError();
 }
