@@ -67,6 +67,13 @@ class _PackedLinear:
         w = self.mod.weight
         return self.cache.get((w,), lambda: ops.pack_conv1d(w.detach().reshape(w.shape[0], w.shape[1], 1)))
 
+    def wp_dgrad(self):
+        """The input-gradient image of the same weight (train.Linear.backward), once per weight version instead of once per AR chunk."""
+        w = self.mod.weight
+        if not hasattr(self, "cache_d"):
+            self.cache_d = _Packed()
+        return self.cache_d.get((w,), lambda: ops.pack_conv1d_dgrad(w.detach().reshape(w.shape[0], w.shape[1], 1)))
+
     def __call__(self, x, residual=None, gelu=False):
         w = self.mod.weight
         b = self.mod.bias.detach() if getattr(self.mod, "bias", None) is not None else None

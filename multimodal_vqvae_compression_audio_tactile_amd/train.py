@@ -34,6 +34,7 @@ class Linear(Function):
         y = packed(x.detach(), residual=residual.detach() if residual is not None else None)
         ctx.save_for_backward(x, w)
         ctx.has_b, ctx.has_res = b is not None, residual is not None
+        ctx.packed = packed if (hasattr(packed, "wp_dgrad") and getattr(getattr(packed, "mod", None), "weight", None) is w) else None
         return y
 
     @staticmethod
@@ -44,7 +45,7 @@ class Linear(Function):
         N = g.shape[-1]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wp = ops.pack_conv1d_dgrad(w.detach().reshape(O, I, 1))
+            wp = ctx.packed.wp_dgrad() if ctx.packed is not None else ops.pack_conv1d_dgrad(w.detach().reshape(O, I, 1))
             gx = ops.conv1d_dgrad(g, wp, I, N, 1)
         if ctx.needs_input_grad[1]:
             gw = ops.linear_wgrad(g.reshape(O, N), x.detach().reshape(I, N)).reshape(w.shape)
