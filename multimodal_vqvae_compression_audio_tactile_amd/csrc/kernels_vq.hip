@@ -1166,13 +1166,18 @@ static hipError_t launch_dac_rvq_lat_t(const float* z, const float* in_w, const 
                                        const float* out_w, const float* out_b, float* zq, int32_t* codes, float* latents,
                                        const int32_t* nq_item, int B, int T, int nq, hipStream_t s, const float* cbn_pre, const float* cn2_pre)
 {
-    // tokens per block: ONE.  Four (the kernel is written for any TOKB) share a stage's 104 KB among four tokens and interleave their
-    // chains, but a stage then takes 12.4 us instead of 6.5 and a quarter as many CUs work: 396 against 240 us for the 75 tokens of
-    // one segment, about equal at 450 tokens (gpurun_out/h8).  What a stage costs is its ~3 000 dependent-issue instructions per
-    // token on a wave that is alone on its SIMD, not the bytes.
-    constexpr int TOKB = 1;
-    hipLaunchKernelGGL((dac_rvq_lat_kernel<CPT, 4, TOKB>), dim3((unsigned)((B * T + TOKB - 1) / TOKB)), dim3(256), 0, s,
-                       z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, cbn_pre, cn2_pre);
+    // Tokens per block: ONE while that is at most one block per CU (N <= 256: the 75 tokens of one segment take 240 us), TWO beyond
+    // (the reference's batch of six is 450 tokens: 225 blocks in one round instead of 450 in two).  Four share a stage's 104 KB
+    // among four tokens and interleave their chains, but a stage then takes 12.4 us instead of 6.5 and a quarter as many CUs work:
+    // 396 against 240 us at 75 tokens (gpurun_out/h8).  What a stage costs is its ~3 000 dependent-issue instructions per token on a
+    // wave that is alone on its SIMD, not the bytes.
+    const int N = B * T;
+    if (N <= 256)
+        hipLaunchKernelGGL((dac_rvq_lat_kernel<CPT, 4, 1>), dim3((unsigned)N), dim3(256), 0, s,
+                           z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, cbn_pre, cn2_pre);
+    else
+        hipLaunchKernelGGL((dac_rvq_lat_kernel<CPT, 4, 2>), dim3((unsigned)((N + 1) / 2)), dim3(256), 0, s,
+                           z, in_w, in_b, cb, out_w, out_b, zq, codes, latents, nq_item, B, T, nq, cbn_pre, cn2_pre);
     return hipGetLastError();
 }
 
