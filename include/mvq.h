@@ -46,7 +46,7 @@ const char* mvq_last_error(void);
  *   0x1 MVQ_TIMING_BUILD, 0x2 MVQ_EXP (pieces of kernels compiled out: results are WRONG by construction), 0x4 MVQ_KGROUP /
  *   MVQ_KPREFETCH, 0x8 MVQ_NO_RES_PREFETCH, 0x10 MVQ_ASM_READS > 1 -- compile-time switches of tools/conv_microbench.py's timing
  *   builds (they do not compile without -DMVQ_TIMING_BUILD); 0x100 MVQ_NO_DMA, 0x200 MVQ_ROWFAST_MAX_KB, 0x400
- *   MVQ_NO_TOKEN_RVQ, 0x800 MVQ_LN_TILE32, 0x1000 MVQ_LAT_MAX_TILES, 0x2000 MVQ_NO_DAC_RVQ_LAT, 0x4000 MVQ_NO_LN_LAT, 0x8000 MVQ_SMALL_TILE_MAX -- environment
+ *   MVQ_NO_TOKEN_RVQ, 0x800 MVQ_LN_TILE32, 0x1000 MVQ_LAT_MAX_TILES, 0x2000 MVQ_NO_DAC_RVQ_LAT, 0x4000 MVQ_NO_LN_LAT, 0x8000 MVQ_SMALL_TILE_MAX, 0x20 MVQ_F16_NO192 / MVQ_F16_NO_WIDE (opt-in f16x3 mode) -- environment
  *   overrides present (results stay correct, timings are not the product's);
  *   0x10000 (informational, not refused) the compiler-scheduled operand loop MVQ_ASM_READS=0.
  * The Python mirror refuses to load a library whose low 16 bits are non-zero unless MVQ_ALLOW_TIMING_BUILD=1;

@@ -174,6 +174,7 @@ unsigned mvq_build_flags(void)
     if (getenv("MVQ_NO_DAC_RVQ_LAT")) mvq::note_env_override(0x2000);
     if (getenv("MVQ_NO_LN_LAT")) mvq::note_env_override(0x4000);
     if (getenv("MVQ_SMALL_TILE_MAX")) mvq::note_env_override(0x8000);
+    if (getenv("MVQ_F16_NO192") || getenv("MVQ_F16_NO_WIDE")) mvq::note_env_override(0x20);      // tile A/B knobs of the opt-in f16x3 mode
     return mvq::conv_compile_flags() | __atomic_load_n(&mvq::g_env_flags, __ATOMIC_RELAXED);
 }
 const char* mvq_last_error(void) { return g_err; }

@@ -610,6 +610,9 @@ hipError_t launch_rvq_ema_forward(const float* z, const float* books, float* q_o
         return o;
     }();
     if (N <= 256 && D == 96 && K <= 512 && (reinterpret_cast<uintptr_t>(books) & 15) == 0 && !no_token_form) {   // CODE_DIM = 96 (Training/...5.py:68)
+        // (Measured and not kept, both bit-equal: both halves of the NEXT book in flight -- does not fit 256 VGPRs beside the half row a
+        // thread keeps; whole rows in LDS, 256 codes per pass, the next pass in flight -- 53 instead of 43 us per 16-token chunk: only
+        // half the threads walk chains, and they are twice as long.  gpurun_out/j1.)
         auto kern = rvq_ema_forward_rows_kernel<24>;
         static BigLdsOptIn opt;                           // per device: 104 KB of dynamic LDS at K = 512
         if (hipError_t e = opt.ensure(reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
