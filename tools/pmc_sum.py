@@ -7,4 +7,4 @@ for d in sys.argv[2:]:
         for r in csv.DictReader(open(f)):
             out[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
             out[r["Kernel_Name"]]["launches@" + r["Counter_Name"]] += 1
-json.dump({k: dict(v) for k, v in out.items() if "conv1d_mfma" in k or "residual_unit" in k}, open(sys.argv[1], "w"), indent=1)
+json.dump({k: dict(v) for k, v in out.items() if "conv1d_mfma" in k or "residual_unit" in k or "conv1d_lat" in k}, open(sys.argv[1], "w"), indent=1)
